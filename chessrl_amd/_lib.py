@@ -1,0 +1,256 @@
+"""ctypes binding of libchessrl_hip.so (the C-ABI in include/chessrl_hip.h).
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU
+is visible, every entry point raises.  ``build()`` compiles the library in-tree
+with hipcc for gfx950 (works without a GPU: hipcc cross-compiles).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "libchessrl_hip.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in
+           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp")]
+HEADER = os.path.join(_ROOT, "include", "chessrl_hip.h")
+
+MAX_MOVES = 256
+N_LABELS = 1968
+PLANES = 128
+NO_MOVE = 0xFFFF
+RESULT_NONE = 2
+FLAG_NUMPY_LEGACY = 1
+
+# every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
+    "crl_max_sims", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
+    "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_results", "crl_records",
+    "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
+    "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
+    "crl_advance", "crl_counters",
+]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> chessrl_amd/libchessrl_hip.so (in-tree)."""
+    srcs = [s for s in SOURCES + [HEADER] if os.path.exists(s)]
+    if not force and os.path.exists(SO_PATH):
+        if not srcs or all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs):
+            return SO_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+           "-shared", "-o", SO_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (never builds implicitly on a GPU box without hipcc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        try:
+            build()
+        except Exception as e:  # pragma: no cover
+            raise HipLibraryError(
+                "libchessrl_hip.so is missing and could not be built with hipcc (%s); "
+                "the HIP path has no CPU fallback" % e)
+    try:
+        L = ctypes.CDLL(SO_PATH)
+    except OSError as e:
+        raise HipLibraryError("cannot load %s: %s" % (SO_PATH, e))
+    vp, i32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
+    L.crl_create.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, u32]
+    L.crl_destroy.argtypes = [vp]
+    L.crl_destroy.restype = None
+    L.crl_set_stream.argtypes = [vp, vp]
+    L.crl_sync.argtypes = [vp]
+    L.crl_last_error.argtypes = [vp]
+    L.crl_last_error.restype = ctypes.c_char_p
+    L.crl_max_games.argtypes = [vp]
+    L.crl_max_sims.argtypes = [vp]
+    L.crl_uci_label_moves.argtypes = [vp]
+    L.crl_reset_games.argtypes = [vp, vp]
+    L.crl_set_positions.argtypes = [vp, vp, i32]
+    L.crl_get_positions.argtypes = [vp, vp, i32]
+    L.crl_legal_moves.argtypes = [vp, vp, vp]
+    L.crl_push_moves.argtypes = [vp, vp, vp]
+    L.crl_results.argtypes = [vp, vp]
+    L.crl_records.argtypes = [vp, vp, vp, vp]
+    L.crl_encode.argtypes = [vp, vp]
+    L.crl_greedy_moves.argtypes = [vp, vp, vp, i32, vp]
+    L.crl_search_begin.argtypes = [vp, vp]
+    L.crl_search_root_priors.argtypes = [vp, vp]
+    L.crl_sim_select_expand.argtypes = [vp, vp, vp, vp]
+    L.crl_sim_reply.argtypes = [vp, vp, vp]
+    L.crl_sim_backup.argtypes = [vp, vp, vp]
+    L.crl_root_children.argtypes = [vp] * 8
+    L.crl_advance.argtypes = [vp, vp, vp, vp]
+    L.crl_counters.argtypes = [vp, vp]
+    for name in SYMBOLS:
+        if name not in ("crl_destroy", "crl_last_error"):
+            getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def uci_label_moves():
+    out = np.zeros(N_LABELS, dtype=np.uint16)
+    rc = lib().crl_uci_label_moves(_ptr(out))
+    if rc != 0:
+        raise HipLibraryError("crl_uci_label_moves failed (%d)" % rc)
+    return out
+
+
+class Context(object):
+    """One crl_ctx (one GPU).  Thin, numpy-in/numpy-out; device pointers are ints."""
+
+    def __init__(self, max_games, max_sims, max_plies=4096, device=0, numpy_legacy=False):
+        self._h = ctypes.c_void_p()
+        self._L = lib()
+        flags = FLAG_NUMPY_LEGACY if numpy_legacy else 0
+        rc = self._L.crl_create(ctypes.byref(self._h), device, max_games, max_sims, max_plies, flags)
+        if rc != 0:
+            msg = self._L.crl_last_error(None)
+            self._h = None
+            raise HipLibraryError("crl_create failed (%d): %s" % (rc, (msg or b"").decode()))
+        self.G, self.max_sims, self.max_plies, self.device = max_games, max_sims, max_plies, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.crl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self._L.crl_last_error(self._h)
+            raise HipLibraryError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.crl_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "crl_set_stream")
+
+    def sync(self):
+        self._ck(self._L.crl_sync(self._h), "crl_sync")
+
+    # ---- Game seam -----------------------------------------------------------------
+    def reset_games(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._ck(self._L.crl_reset_games(self._h, _ptr(m)), "crl_reset_games")
+
+    def set_positions(self, boards):
+        """boards: np.uint64 [n][8] rows (bb0..5, white, state)."""
+        b = np.ascontiguousarray(boards, dtype=np.uint64).reshape(-1, 8)
+        self._ck(self._L.crl_set_positions(self._h, _ptr(b), b.shape[0]), "crl_set_positions")
+
+    def get_positions(self, n=None):
+        n = self.G if n is None else n
+        b = np.zeros((n, 8), dtype=np.uint64)
+        self._ck(self._L.crl_get_positions(self._h, _ptr(b), n), "crl_get_positions")
+        return b
+
+    def legal_moves(self):
+        moves = np.zeros((self.G, MAX_MOVES), dtype=np.uint16)
+        counts = np.zeros(self.G, dtype=np.int32)
+        self._ck(self._L.crl_legal_moves(self._h, _ptr(moves), _ptr(counts)), "crl_legal_moves")
+        return moves, counts
+
+    def push_moves(self, moves):
+        m = np.ascontiguousarray(moves, dtype=np.uint16)
+        assert m.shape == (self.G,)
+        ok = np.zeros(self.G, dtype=np.uint8)
+        self._ck(self._L.crl_push_moves(self._h, _ptr(m), _ptr(ok)), "crl_push_moves")
+        return ok
+
+    def results(self):
+        r = np.zeros(self.G, dtype=np.int8)
+        self._ck(self._L.crl_results(self._h, _ptr(r)), "crl_results")
+        return r
+
+    def records(self, with_moves=True):
+        moves = np.zeros((self.G, self.max_plies), dtype=np.uint16) if with_moves else None
+        plies = np.zeros(self.G, dtype=np.int32)
+        res = np.zeros(self.G, dtype=np.int8)
+        self._ck(self._L.crl_records(self._h, _ptr(moves), _ptr(plies), _ptr(res)), "crl_records")
+        return moves, plies, res
+
+    # ---- encoder / agent seam (device pointers) ----------------------------------------
+    def encode(self, dev_planes):
+        self._ck(self._L.crl_encode(self._h, ctypes.c_void_p(dev_planes)), "crl_encode")
+
+    def greedy_moves(self, dev_policy, mask=None, push=False, want_moves=True):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        out = np.zeros(self.G, dtype=np.uint16) if want_moves else None
+        self._ck(self._L.crl_greedy_moves(self._h, ctypes.c_void_p(dev_policy), _ptr(m),
+                                          1 if push else 0, _ptr(out)), "crl_greedy_moves")
+        return out
+
+    # ---- SelfPlayTree seam -------------------------------------------------------------
+    def search_begin(self, dev_planes):
+        self._ck(self._L.crl_search_begin(self._h, ctypes.c_void_p(dev_planes)), "crl_search_begin")
+
+    def search_root_priors(self, dev_policy):
+        self._ck(self._L.crl_search_root_priors(self._h, ctypes.c_void_p(dev_policy)),
+                 "crl_search_root_priors")
+
+    def sim_select_expand(self, dev_policy_s2, dev_value_s2, dev_planes_s1):
+        self._ck(self._L.crl_sim_select_expand(
+            self._h, ctypes.c_void_p(dev_policy_s2), ctypes.c_void_p(dev_value_s2),
+            ctypes.c_void_p(dev_planes_s1)), "crl_sim_select_expand")
+
+    def sim_reply(self, dev_policy_s1, dev_planes_s2):
+        self._ck(self._L.crl_sim_reply(self._h, ctypes.c_void_p(dev_policy_s1),
+                                       ctypes.c_void_p(dev_planes_s2)), "crl_sim_reply")
+
+    def sim_backup(self, dev_policy_s2, dev_value_s2):
+        self._ck(self._L.crl_sim_backup(self._h, ctypes.c_void_p(dev_policy_s2),
+                                        ctypes.c_void_p(dev_value_s2)), "crl_sim_backup")
+
+    def root_children(self):
+        G = self.G
+        out = {
+            "nchild": np.zeros(G, np.int32), "visits": np.zeros((G, MAX_MOVES), np.int32),
+            "values": np.zeros((G, MAX_MOVES), np.float64), "priors": np.zeros((G, MAX_MOVES), np.float32),
+            "moves": np.zeros((G, MAX_MOVES), np.uint16), "replies": np.zeros((G, MAX_MOVES), np.uint16),
+            "root_visits": np.zeros(G, np.int32),
+        }
+        self._ck(self._L.crl_root_children(
+            self._h, _ptr(out["nchild"]), _ptr(out["visits"]), _ptr(out["values"]), _ptr(out["priors"]),
+            _ptr(out["moves"]), _ptr(out["replies"]), _ptr(out["root_visits"])), "crl_root_children")
+        return out
+
+    def advance(self, chosen):
+        c = np.ascontiguousarray(chosen, dtype=np.int32)
+        assert c.shape == (self.G,)
+        bm = np.zeros(self.G, np.uint16)
+        am = np.zeros(self.G, np.uint16)
+        self._ck(self._L.crl_advance(self._h, _ptr(c), _ptr(bm), _ptr(am)), "crl_advance")
+        return bm, am
+
+    def counters(self):
+        c = np.zeros(6, dtype=np.uint64)
+        self._ck(self._L.crl_counters(self._h, _ptr(c)), "crl_counters")
+        return dict(zip(("sims", "nodes", "depth_sum", "branch_sum", "evals", "terminal_hits"),
+                        (int(x) for x in c)))

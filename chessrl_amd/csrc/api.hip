@@ -1,0 +1,428 @@
+// api.hip -- host side of libchessrl_hip.so: context, HBM pools, kernel launches and the
+// C-ABI declared in include/chessrl_hip.h.  gfx950 only; no torch types cross this boundary.
+#include "../../include/chessrl_hip.h"
+#include "search.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace crl;
+
+static_assert(sizeof(crl_board) == sizeof(Board), "crl_board layout");
+static_assert(CRL_MAX_MOVES == MAX_MOVES && CRL_N_LABELS == N_LABELS && CRL_PLANES == PLANES,
+              "header constants");
+
+static thread_local std::string g_create_error;
+
+struct crl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev d{};
+    std::vector<void *> allocs;
+    std::string error;
+    // device staging for host-facing calls
+    u16 *t_moves = nullptr;       // [G][256]
+    u16 *t_moves2 = nullptr;      // [G][256]
+    int32_t *t_i32a = nullptr;    // [G][256]
+    int32_t *t_i32b = nullptr;    // [G]
+    int32_t *t_i32c = nullptr;    // [G]
+    double *t_f64 = nullptr;      // [G][256]
+    float *t_f32 = nullptr;       // [G][256]
+    uint8_t *t_u8 = nullptr;      // [G]
+    u16 *t_u16a = nullptr;        // [G]
+    u16 *t_u16b = nullptr;        // [G]
+    Board *t_boards = nullptr;    // [G]
+};
+
+// ---- netencoder.get_uci_labels (netencoder.py:94-134) as move ids ------------------------------
+// Order is the contract: per from-square (file-major), destinations along the rank, the file,
+// the a1-h8 diagonal, the h1-a8 diagonal, then 8 knight jumps; then per file the under-/promotion
+// labels q,r,b,n x {straight, capture towards a, capture towards h} x {rank 2->1, rank 7->8}.
+static void build_labels(std::vector<u16> &labels)
+{
+    labels.clear();
+    static const int kn[8][2] = { { -2, -1 }, { -1, -2 }, { -2, 1 }, { 1, -2 },
+                                  { 2, -1 }, { -1, 2 }, { 2, 1 }, { 1, 2 } };
+    for (int f = 0; f < 8; f++)
+        for (int r = 0; r < 8; r++) {
+            std::vector<std::pair<int, int>> dst;
+            for (int t = 0; t < 8; t++) dst.push_back({ t, r });
+            for (int t = 0; t < 8; t++) dst.push_back({ f, t });
+            for (int t = -7; t < 8; t++) dst.push_back({ f + t, r + t });
+            for (int t = -7; t < 8; t++) dst.push_back({ f + t, r - t });
+            for (auto &k : kn) dst.push_back({ f + k[0], r + k[1] });
+            for (auto &q : dst) {
+                if (q.first == f && q.second == r) continue;
+                if (q.first < 0 || q.first > 7 || q.second < 0 || q.second > 7) continue;
+                labels.push_back((u16)((r * 8 + f) | ((q.second * 8 + q.first) << 6)));
+            }
+        }
+    static const int promo_code[4] = { 5, 4, 3, 2 };       // q r b n
+    for (int f = 0; f < 8; f++)
+        for (int pi = 0; pi < 4; pi++) {
+            const int pc = promo_code[pi] << 12;
+            labels.push_back((u16)((8 + f) | ((0 + f) << 6) | pc));
+            labels.push_back((u16)((48 + f) | ((56 + f) << 6) | pc));
+            if (f > 0) {
+                labels.push_back((u16)((8 + f) | ((0 + f - 1) << 6) | pc));
+                labels.push_back((u16)((48 + f) | ((56 + f - 1) << 6) | pc));
+            }
+            if (f < 7) {
+                labels.push_back((u16)((8 + f) | ((0 + f + 1) << 6) | pc));
+                labels.push_back((u16)((48 + f) | ((56 + f + 1) << 6) | pc));
+            }
+        }
+}
+
+static int fail(crl_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            return fail(ctx, CRL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(crl_ctx *ctx, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    ctx->allocs.push_back(q);
+    if (zero) {
+        e = hipMemset(q, 0, bytes);
+        if (e != hipSuccess) return e;
+    }
+    *p = (T *)q;
+    return hipSuccess;
+}
+
+static const char *dev_err_name(int c)
+{
+    switch (c) {
+    case DERR_NODE_POOL: return "node pool overflow (more than max_sims+1 nodes in one tree)";
+    case DERR_EDGE_POOL: return "edge pool overflow";
+    case DERR_PLY_POOL: return "game longer than max_plies";
+    case DERR_STATE: return "search call out of order (reply/backup/advance state machine)";
+    case DERR_BRANCH: return "more than 256 legal moves";
+    case DERR_LABEL: return "legal move without a policy label";
+    default: return "unknown device error";
+    }
+}
+
+static int check_dev_error(crl_ctx *ctx)
+{
+    int32_t e = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&e, ctx->d.err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e != 0) return fail(ctx, e == DERR_STATE ? CRL_ERR_STATE : CRL_ERR_CAPACITY, dev_err_name(e));
+    return CRL_OK;
+}
+
+#define LAUNCH(ctx, kern, ...)                                                          \
+    do {                                                                                \
+        hipLaunchKernelGGL(kern, dim3((ctx)->d.G), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
+        HIP_TRY(ctx, hipGetLastError());                                                \
+    } while (0)
+
+extern "C" {
+
+int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_plies, uint32_t flags)
+{
+    if (!out || max_games < 1 || max_sims < 1 || max_sims > 32000 || max_plies < 2)
+        return fail(nullptr, CRL_ERR_ARG, "crl_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, CRL_ERR_HIP, "crl_create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, CRL_ERR_ARG, "crl_create: bad device index");
+    crl_ctx *ctx = new crl_ctx();
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e)); }
+    Dev &d = ctx->d;
+    d.G = max_games;
+    d.N = max_sims + 1;
+    d.ECAP = d.N * MAX_BRANCH;
+    d.MAXPLY = max_plies;
+    d.flags = flags;
+    const size_t G = d.G, GN = G * d.N, GE = G * (size_t)d.ECAP;
+    bool ok = true;
+#define A(ptr, count) ok = ok && (dalloc(ctx, &(ptr), (count)) == hipSuccess)
+#define AN(ptr, count) ok = ok && (dalloc(ctx, &(ptr), (count), false) == hipSuccess)
+    A(d.cur, G); A(d.ply, G); A(d.hist, G * HIST_RING); A(d.hist_hash, G * HIST_RING);
+    A(d.rec_moves, G * (size_t)d.MAXPLY); A(d.game_result, G);
+    A(d.n_nodes, G); A(d.edge_top, G); A(d.root_visits, G); A(d.root_dead, G);
+    AN(d.meta, GN); AN(d.nb1, GN); AN(d.nb2, GN); AN(d.nh1, GN); AN(d.nh2, GN); AN(d.n_reply, GN);
+    AN(d.e_move, GE); AN(d.e_child, GE); AN(d.e_visits, GE); AN(d.e_prior, GE); AN(d.e_value, GE);
+    A(d.path_len, G); AN(d.path_edge, GN); AN(d.path_node, GN); A(d.leaf_node, G); A(d.leaf_kind, G);
+    A(d.s1_moves, G * MAX_MOVES); A(d.s1_n, G);
+    A(d.counters, G * CNT_N); A(d.err, 1);
+    A(ctx->t_moves, G * MAX_MOVES); A(ctx->t_moves2, G * MAX_MOVES); A(ctx->t_i32a, G * MAX_MOVES);
+    A(ctx->t_i32b, G); A(ctx->t_i32c, G); A(ctx->t_f64, G * MAX_MOVES); A(ctx->t_f32, G * MAX_MOVES);
+    A(ctx->t_u8, G); A(ctx->t_u16a, G); A(ctx->t_u16b, G); A(ctx->t_boards, G);
+    u16 *lut = nullptr;
+    A(lut, 5 * 4096);
+#undef A
+#undef AN
+    if (!ok) {
+        std::string msg = "crl_create: hipMalloc failed (pools need about " +
+                          std::to_string((GE * 20 + GN * 170) >> 20) + " MiB)";
+        for (void *p : ctx->allocs) (void)hipFree(p);
+        delete ctx;
+        return fail(nullptr, CRL_ERR_HIP, msg);
+    }
+    std::vector<u16> labels;
+    build_labels(labels);
+    std::vector<u16> h(5 * 4096, 0xFFFF);
+    for (size_t i = 0; i < labels.size(); i++) {
+        u32 mv = labels[i], p = (mv >> 12) & 7, slot = p ? 6 - p : 0;
+        h[slot * 4096 + (mv & 4095)] = (u16)i;
+    }
+    e = hipMemcpy(lut, h.data(), h.size() * sizeof(u16), hipMemcpyHostToDevice);
+    d.lut = lut;
+    if (e != hipSuccess || labels.size() != N_LABELS) {
+        for (void *p : ctx->allocs) (void)hipFree(p);
+        delete ctx;
+        return fail(nullptr, CRL_ERR_HIP, "crl_create: label table upload failed");
+    }
+    *out = ctx;
+    int rc = crl_reset_games(ctx, nullptr);
+    if (rc == CRL_OK) rc = crl_sync(ctx);
+    if (rc != CRL_OK) { g_create_error = ctx->error; crl_destroy(ctx); *out = nullptr; }
+    return rc;
+}
+
+void crl_destroy(crl_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : ctx->allocs) (void)hipFree(p);
+    delete ctx;
+}
+
+int crl_set_stream(crl_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return CRL_ERR_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return CRL_OK;
+}
+
+int crl_sync(crl_ctx *ctx)
+{
+    if (!ctx) return CRL_ERR_ARG;
+    return check_dev_error(ctx);
+}
+
+const char *crl_last_error(crl_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+int crl_max_games(crl_ctx *ctx) { return ctx ? ctx->d.G : CRL_ERR_ARG; }
+int crl_max_sims(crl_ctx *ctx) { return ctx ? ctx->d.N - 1 : CRL_ERR_ARG; }
+
+int crl_uci_label_moves(uint16_t *moves_out)
+{
+    if (!moves_out) return CRL_ERR_ARG;
+    std::vector<u16> labels;
+    build_labels(labels);
+    if (labels.size() != N_LABELS) return CRL_ERR_STATE;
+    memcpy(moves_out, labels.data(), N_LABELS * sizeof(u16));
+    return CRL_OK;
+}
+
+// ---- Game seam ----------------------------------------------------------------------------
+int crl_reset_games(crl_ctx *ctx, const uint8_t *mask)
+{
+    if (!ctx) return CRL_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint8_t *dm = nullptr;
+    if (mask) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->d.G, hipMemcpyHostToDevice, ctx->stream));
+        dm = ctx->t_u8;
+    }
+    LAUNCH(ctx, k_set_positions, ctx->d, (const Board *)nullptr, dm, ctx->d.G, 1);
+    if (mask) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host mask may be freed by caller
+    return CRL_OK;
+}
+
+int crl_set_positions(crl_ctx *ctx, const crl_board *boards, int n)
+{
+    if (!ctx || !boards || n < 0 || n > ctx->d.G) return fail(ctx, CRL_ERR_ARG, "crl_set_positions: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_boards, boards, (size_t)n * sizeof(Board), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, k_set_positions, ctx->d, (const Board *)ctx->t_boards, (const uint8_t *)nullptr, n, 0);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CRL_OK;
+}
+
+int crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n)
+{
+    if (!ctx || !boards_out || n < 0 || n > ctx->d.G) return fail(ctx, CRL_ERR_ARG, "crl_get_positions: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(boards_out, ctx->d.cur, (size_t)n * sizeof(Board), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CRL_OK;
+}
+
+int crl_legal_moves(crl_ctx *ctx, uint16_t *moves, int32_t *counts)
+{
+    if (!ctx || !moves || !counts) return fail(ctx, CRL_ERR_ARG, "crl_legal_moves: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->d.G;
+    LAUNCH(ctx, k_legal_moves, ctx->d, ctx->t_moves, ctx->t_i32b);
+    HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->t_moves, G * MAX_MOVES * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->t_i32b, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return check_dev_error(ctx);
+}
+
+int crl_push_moves(crl_ctx *ctx, const uint16_t *moves, uint8_t *ok)
+{
+    if (!ctx || !moves || !ok) return fail(ctx, CRL_ERR_ARG, "crl_push_moves: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->d.G;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u16a, moves, G * sizeof(u16), hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, k_push, ctx->d, (const u16 *)ctx->t_u16a, ctx->t_u8);
+    HIP_TRY(ctx, hipMemcpyAsync(ok, ctx->t_u8, G, hipMemcpyDeviceToHost, ctx->stream));
+    return check_dev_error(ctx);
+}
+
+int crl_results(crl_ctx *ctx, int8_t *result)
+{
+    if (!ctx || !result) return fail(ctx, CRL_ERR_ARG, "crl_results: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result, ctx->d.G, hipMemcpyDeviceToHost, ctx->stream));
+    return check_dev_error(ctx);
+}
+
+int crl_records(crl_ctx *ctx, uint16_t *moves, int32_t *plies, int8_t *result)
+{
+    if (!ctx || !plies) return fail(ctx, CRL_ERR_ARG, "crl_records: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->d.G;
+    if (moves)
+        HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->d.rec_moves, G * ctx->d.MAXPLY * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->d.ply, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (result)
+        HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result, G, hipMemcpyDeviceToHost, ctx->stream));
+    return check_dev_error(ctx);
+}
+
+int crl_encode(crl_ctx *ctx, void *dev_planes_f16)
+{
+    if (!ctx || !dev_planes_f16) return fail(ctx, CRL_ERR_ARG, "crl_encode: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_encode_cur, ctx->d, dev_planes_f16);
+    return CRL_OK;
+}
+
+int crl_greedy_moves(crl_ctx *ctx, const void *dev_policy_f32, const uint8_t *mask, int push, uint16_t *moves_out)
+{
+    if (!ctx || !dev_policy_f32) return fail(ctx, CRL_ERR_ARG, "crl_greedy_moves: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint8_t *dm = nullptr;
+    if (mask) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->d.G, hipMemcpyHostToDevice, ctx->stream));
+        dm = ctx->t_u8;
+    }
+    LAUNCH(ctx, k_greedy, ctx->d, (const float *)dev_policy_f32, dm, push, ctx->t_u16a);
+    if (moves_out)
+        HIP_TRY(ctx, hipMemcpyAsync(moves_out, ctx->t_u16a, (size_t)ctx->d.G * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+    if (mask || moves_out) return check_dev_error(ctx);
+    return CRL_OK;
+}
+
+// ---- SelfPlayTree seam ----------------------------------------------------------------------
+int crl_search_begin(crl_ctx *ctx, void *dev_planes_f16)
+{
+    if (!ctx || !dev_planes_f16) return fail(ctx, CRL_ERR_ARG, "crl_search_begin: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_search_begin, ctx->d, dev_planes_f16);
+    return CRL_OK;
+}
+
+int crl_search_root_priors(crl_ctx *ctx, const void *dev_policy_f32)
+{
+    if (!ctx || !dev_policy_f32) return fail(ctx, CRL_ERR_ARG, "crl_search_root_priors: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_root_priors, ctx->d, (const float *)dev_policy_f32);
+    return CRL_OK;
+}
+
+int crl_sim_select_expand(crl_ctx *ctx, const void *dev_policy_s2_f32, const void *dev_value_s2_f32,
+                          void *dev_planes_s1_f16)
+{
+    if (!ctx || !dev_planes_s1_f16) return fail(ctx, CRL_ERR_ARG, "crl_sim_select_expand: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_select_expand, ctx->d, (const float *)dev_policy_s2_f32, (const float *)dev_value_s2_f32,
+           dev_planes_s1_f16);
+    return CRL_OK;
+}
+
+int crl_sim_reply(crl_ctx *ctx, const void *dev_policy_s1_f32, void *dev_planes_s2_f16)
+{
+    if (!ctx || !dev_policy_s1_f32 || !dev_planes_s2_f16) return fail(ctx, CRL_ERR_ARG, "crl_sim_reply: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_reply, ctx->d, (const float *)dev_policy_s1_f32, dev_planes_s2_f16);
+    return CRL_OK;
+}
+
+int crl_sim_backup(crl_ctx *ctx, const void *dev_policy_s2_f32, const void *dev_value_s2_f32)
+{
+    if (!ctx || !dev_policy_s2_f32 || !dev_value_s2_f32) return fail(ctx, CRL_ERR_ARG, "crl_sim_backup: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LAUNCH(ctx, k_backup, ctx->d, (const float *)dev_policy_s2_f32, (const float *)dev_value_s2_f32);
+    return CRL_OK;
+}
+
+int crl_root_children(crl_ctx *ctx, int32_t *nchild, int32_t *visits, double *values, float *priors,
+                      uint16_t *moves, uint16_t *replies, int32_t *root_visits)
+{
+    if (!ctx) return CRL_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->d.G, R = G * MAX_MOVES;
+    LAUNCH(ctx, k_root_children, ctx->d, ctx->t_i32b, ctx->t_i32a, ctx->t_f64, ctx->t_f32, ctx->t_moves,
+           ctx->t_moves2, ctx->t_i32c);
+    hipStream_t s = ctx->stream;
+    if (nchild) HIP_TRY(ctx, hipMemcpyAsync(nchild, ctx->t_i32b, G * 4, hipMemcpyDeviceToHost, s));
+    if (visits) HIP_TRY(ctx, hipMemcpyAsync(visits, ctx->t_i32a, R * 4, hipMemcpyDeviceToHost, s));
+    if (values) HIP_TRY(ctx, hipMemcpyAsync(values, ctx->t_f64, R * 8, hipMemcpyDeviceToHost, s));
+    if (priors) HIP_TRY(ctx, hipMemcpyAsync(priors, ctx->t_f32, R * 4, hipMemcpyDeviceToHost, s));
+    if (moves) HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->t_moves, R * 2, hipMemcpyDeviceToHost, s));
+    if (replies) HIP_TRY(ctx, hipMemcpyAsync(replies, ctx->t_moves2, R * 2, hipMemcpyDeviceToHost, s));
+    if (root_visits) HIP_TRY(ctx, hipMemcpyAsync(root_visits, ctx->t_i32c, G * 4, hipMemcpyDeviceToHost, s));
+    return check_dev_error(ctx);
+}
+
+int crl_advance(crl_ctx *ctx, const int32_t *chosen, uint16_t *bm, uint16_t *am)
+{
+    if (!ctx || !chosen) return fail(ctx, CRL_ERR_ARG, "crl_advance: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->d.G;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_i32b, chosen, G * 4, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, k_advance, ctx->d, (const int32_t *)ctx->t_i32b, ctx->t_u16a, ctx->t_u16b);
+    if (bm) HIP_TRY(ctx, hipMemcpyAsync(bm, ctx->t_u16a, G * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (am) HIP_TRY(ctx, hipMemcpyAsync(am, ctx->t_u16b, G * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return check_dev_error(ctx);
+}
+
+int crl_counters(crl_ctx *ctx, uint64_t *out6)
+{
+    if (!ctx || !out6) return CRL_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<unsigned long long> h((size_t)ctx->d.G * CNT_N);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->d.counters, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < CNT_N; k++) out6[k] = 0;
+    for (int g = 0; g < ctx->d.G; g++)
+        for (int k = 0; k < CNT_N; k++) out6[k] += h[(size_t)g * CNT_N + k];
+    return CRL_OK;
+}
+
+}  // extern "C"

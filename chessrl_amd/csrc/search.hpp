@@ -1,0 +1,608 @@
+// search.hpp -- device kernels of the lockstep self-play simulation loop.
+//
+// One 64-lane wavefront (one 64-thread workgroup) per game.  Reference symbols
+// (paths relative to /root/reference/src/chessrl/):
+//
+//   k_search_begin     Tree.__init__                          mctree.py:105-111
+//   k_root_priors      _update_prior for the root             mctree.py:298-303
+//   k_select_expand    backprop (pending) + select + expand   mctree.py:216-257,278-296
+//   k_reply            opponent reply half of expand, Node()  mctree.py:244-250,28-37
+//   k_backup           simulate + backprop + child priors     mctree.py:259-303
+//   k_root_children    [c.visits for c in root.children]      mctree.py:178,313-315
+//   k_advance          gam.move(bm); gam.move(am)             selfplay.py:77-78
+//   k_encode_cur       netencoder.get_game_state              netencoder.py:72-91
+//   k_legal/k_push/... Game.get_legal_moves/move/get_result   game.py:28-57,92-109
+//   k_greedy           AgentDistributed.best_move(real_game)  agentdistributed.py:56-58
+//
+// Float contract of get_value (mctree.py:71-87), reproduced with explicit
+// round-to-nearest intrinsics (and the file is built with -ffp-contract=off):
+//   Q = value / (1 + visits)                       float64 divide
+//   U = (10 * prior) * (sqrt(sum) / (1 + visits))  10*prior in float32 (numpy>=2) or
+//                                                  float64 (numpy 1.x flag); rest float64
+//   sum = visits of the child's own children = visits-1 (0 for a terminal child), which
+//   is exact in sequential mode: every simulation through a non-terminal node after the
+//   one that created it visits exactly one of its children.
+#pragma once
+#include "movegen.hpp"
+#include "state.hpp"
+
+namespace crl {
+
+struct WaveLds {
+    u16 mv[MAX_MOVES];
+    Board enc[9];
+    u64 pl[PLANES];
+};
+
+__device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// ---- where does the position `tp` tree-plies after the root live? -------------------------
+// tp >= 1: node path_node[(tp+1)/2], S1 if tp is odd else S2.  tp <= 0: game history ring
+// at ply ply0 + tp, where ply0 is the game ply of tree-ply 0.
+struct PastRef { const Board *b; const u64 *h; bool valid; };
+
+__device__ inline PastRef past_ref(const Dev &d, int g, int tp, int ply0, int ply_ring_top)
+{
+    PastRef r;
+    if (tp >= 1) {
+        int node = d.path_node[(size_t)g * d.N + ((tp + 1) >> 1)];
+        size_t ni = (size_t)g * d.N + node;
+        r.b = (tp & 1) ? d.nb1 + ni : d.nb2 + ni;
+        r.h = (tp & 1) ? d.nh1 + ni : d.nh2 + ni;
+        r.valid = true;
+    } else {
+        int p = ply0 + tp;
+        r.valid = p >= 0 && p > ply_ring_top - HIST_RING && p <= ply_ring_top;
+        size_t hi = (size_t)g * HIST_RING + (p & (HIST_RING - 1));
+        r.b = d.hist + hi;
+        r.h = d.hist_hash + hi;
+    }
+    return r;
+}
+
+// earlier occurrences of position b (python-chess is_repetition: same _transposition_key),
+// looking back over the reversible plies only; lanes test distances 2,4,6,... in parallel
+__device__ inline int count_prior(const Dev &d, int g, const Board &b, u64 h, int tp, int ply0,
+                                  int ring_top, int lane)
+{
+    const int clock = (int)st_clock(b.state);
+    int cnt = 0;
+    if (clock < 8) return 0;                 // a 5th occurrence needs >= 8 reversible plies
+    for (int base = 0; 2 * (base + 1) <= clock; base += 64) {
+        const int dist = 2 * (base + lane + 1);
+        bool hit = false;
+        if (dist <= clock) {
+            PastRef r = past_ref(d, g, tp - dist, ply0, ring_top);
+            if (r.valid && *r.h == h) {
+                Board o = *r.b;
+                hit = same_key(o, b);
+            }
+        }
+        cnt += popc(__ballot(hit));
+    }
+    return cnt;
+}
+
+struct PosEval { Board b; u64 hash; int n; int result; };
+
+// legal moves (into s.mv), derived ep bit, hash, repetition and Game.get_result of `b`
+__device__ inline PosEval eval_position(const Dev &d, int g, Board b, int tp, int ply0,
+                                        int ring_top, int lane, WaveLds &s)
+{
+    MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+    b.state = (b.state & ~(1u << 20)) | ((mi.ep_legal ? 1u : 0u) << 20);
+    PosEval e;
+    e.hash = board_hash(b);
+    int rep = 1 + count_prior(d, g, b, e.hash, tp, ply0, ring_top, lane);
+    e.result = position_result(b, mi.n, mi.in_check, rep);
+    e.n = mi.n;
+    e.b = b;
+    __syncthreads();                          // s.mv visible to every lane
+    return e;
+}
+
+// ---- netencoder.get_game_state (netencoder.py:13-91) -> fp16 NHWC [8][8][128] ----------------
+// Channels: 0-6 black {no black piece here, P,N,B,R,Q,K}, 7-13 white likewise, then the same
+// 14 planes for each of the 8 previous positions (zeros where the move stack is shorter),
+// 126 = side to move is white, 127 = zero pad.  Row 0 = rank 8: spatial index = sq ^ 56.
+// Lane l always owns channel group l&15, so its 8 plane bitboards stay in registers; each of the
+// 16 store iterations writes one contiguous 1 KiB per wave.
+__device__ inline void encode_position(const Dev &d, int g, const Board &b, int tp, int ply0,
+                                       int ring_top, int lane, WaveLds &s, void *planes_out)
+{
+    bool valid = false;
+    if (lane < 9) {
+        Board e = b;
+        valid = true;
+        if (lane > 0) {
+            PastRef r = past_ref(d, g, tp - lane, ply0, ring_top);
+            valid = r.valid;
+            if (valid) e = *r.b;
+        }
+        s.enc[lane] = e;
+    }
+    const u32 vmask = (u32)__ballot(valid);
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int c = lane + 64 * half;
+        u64 v = 0;
+        if (c < 126) {
+            const int i = c / 14, k = c % 14, t = k % 7;
+            const Board &e = s.enc[i];
+            const u64 occ = occupied(e);
+            const u64 own = k >= 7 ? e.white : (occ & ~e.white);
+            if ((vmask >> i) & 1) v = t == 0 ? ~own : (e.bb[t - 1] & own);
+        } else if (c == 126) {
+            v = st_turn(b.state) ? ~0ull : 0ull;
+        }
+        s.pl[c] = v;
+    }
+    __syncthreads();
+    const int cg = lane & 15;
+    u64 p8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) p8[k] = s.pl[cg * 8 + k];
+    uint4 *out = (uint4 *)planes_out + (size_t)g * (64 * PLANES * 2 / 16);
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int sq = (t * 4 + (lane >> 4)) ^ 56;
+        u32 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            w[k] = (((p8[2 * k] >> sq) & 1) ? 0x3C00u : 0u) |
+                   (((p8[2 * k + 1] >> sq) & 1) ? 0x3C000000u : 0u);
+        out[t * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+}
+
+// ---- shared pieces ---------------------------------------------------------------------------
+__device__ inline void dev_error(const Dev &d, int code)
+{
+    atomicCAS(d.err, 0, code);
+}
+
+__device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, const u16 *mv, int lane)
+{
+    for (int j = lane; j < n; j += 64) {
+        size_t e = eb + edge0 + j;
+        d.e_move[e] = mv[j];
+        d.e_child[e] = CHILD_NONE;
+        d.e_visits[e] = 0;
+        d.e_value[e] = 0.0;
+        d.e_prior[e] = 1.0f;                 // Node.prior = 1 (mctree.py:35)
+    }
+}
+
+__device__ inline void gather_priors(const Dev &d, int g, size_t eb, int edge0, int n,
+                                     const float *pol, int lane)
+{
+    for (int j = lane; j < n; j += 64) {
+        size_t e = eb + edge0 + j;
+        int lab = label_of(d, d.e_move[e]);
+        if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
+        d.e_prior[e] = pol[(size_t)g * N_LABELS + lab];
+    }
+}
+
+// index of the first maximum of policy[label(m)] over the n moves in mv (np.argmax)
+__device__ inline int argmax_policy(const Dev &d, int g, const u16 *mv, int n, const float *pol,
+                                    int lane)
+{
+    float best = -__builtin_inff();
+    int bi = 0x7FFFFFFF;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        if (i < n) {
+            int lab = label_of(d, mv[i]);
+            if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
+            float p = pol[(size_t)g * N_LABELS + lab];
+            if (p > best || bi == 0x7FFFFFFF) { best = p; bi = i; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        float ob = __shfl_xor(best, o);
+        int oi = __shfl_xor(bi, o);
+        bool take = oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || ob > best || (ob == best && oi < bi));
+        if (take) { best = ob; bi = oi; }
+    }
+    return bi;
+}
+
+// push a legal move onto the game (python-chess Board.push + result bookkeeping)
+__device__ inline void game_push(const Dev &d, int g, const Board &b, u32 mv, int lane, WaveLds &s)
+{
+    const int p = d.ply[g];
+    Board nb = apply_move(b, mv);
+    PosEval e = eval_position(d, g, nb, 0, p + 1, p, lane, s);
+    if (lane == 0) {
+        if (p + 1 > d.MAXPLY) { dev_error(d, DERR_PLY_POOL); }
+        else {
+            size_t hi = (size_t)g * HIST_RING + ((p + 1) & (HIST_RING - 1));
+            d.hist[hi] = e.b;
+            d.hist_hash[hi] = e.hash;
+            d.rec_moves[(size_t)g * d.MAXPLY + p] = (u16)mv;
+            d.cur[g] = e.b;
+            d.ply[g] = p + 1;
+            d.game_result[g] = (int8_t)e.result;
+            d.root_dead[g] = 1;
+        }
+    }
+}
+
+// ---- Game seam kernels -------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_set_positions(Dev d, const Board *in, const uint8_t *mask,
+                                                      int n, int use_start)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n || (mask && !mask[g])) return;
+    Board b;
+    if (use_start) {
+        b.bb[PAWN] = 0x00FF00000000FF00ull; b.bb[KNIGHT] = 0x4200000000000042ull;
+        b.bb[BISHOP] = 0x2400000000000024ull; b.bb[ROOK] = 0x8100000000000081ull;
+        b.bb[QUEEN] = 0x0800000000000008ull; b.bb[KING] = 0x1000000000000010ull;
+        b.white = 0xFFFFull;
+        b.state = mk_state(1, 15, NO_EP, 0, 0);
+        b.pad = 0;
+    } else {
+        b = in[g];
+        b.state &= 0xFFFFFu;
+        b.pad = 0;
+    }
+    if (lane == 0) d.ply[g] = 0;
+    PosEval e = eval_position(d, g, b, 0, 0, -1, lane, s);
+    if (lane == 0) {
+        d.cur[g] = e.b;
+        d.hist[(size_t)g * HIST_RING] = e.b;
+        d.hist_hash[(size_t)g * HIST_RING] = e.hash;
+        d.game_result[g] = (int8_t)e.result;
+        d.root_dead[g] = 1;
+        d.leaf_kind[g] = LEAF_NONE;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_legal_moves(Dev d, u16 *moves, int32_t *counts)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Board b = d.cur[g];
+    MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+    __syncthreads();
+    for (int j = lane; j < mi.n; j += 64) moves[(size_t)g * MAX_MOVES + j] = s.mv[j];
+    if (lane == 0) counts[g] = mi.n;
+}
+
+__global__ __launch_bounds__(64) void k_push(Dev d, const u16 *moves, uint8_t *ok)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const u32 mv = moves[g];
+    if (mv == NO_MOVE) { if (lane == 0) ok[g] = 0; return; }
+    Board b = d.cur[g];
+    MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+    __syncthreads();
+    bool found = false;
+    for (int j = lane; j < mi.n; j += 64) found = found || s.mv[j] == mv;
+    const bool legal = __ballot(found) != 0;
+    __syncthreads();
+    if (lane == 0) ok[g] = legal ? 1 : 0;
+    if (legal) game_push(d, g, b, mv, lane, s);
+}
+
+__global__ __launch_bounds__(64) void k_encode_cur(Dev d, void *planes)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Board b = d.cur[g];
+    const int p = d.ply[g];
+    encode_position(d, g, b, 0, p, p, lane, s, planes);
+}
+
+__global__ __launch_bounds__(64) void k_greedy(Dev d, const float *pol, const uint8_t *mask,
+                                               int push, u16 *moves_out)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (lane == 0) moves_out[g] = NO_MOVE;
+    if (mask && !mask[g]) return;
+    Board b = d.cur[g];
+    MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+    __syncthreads();
+    if (mi.n == 0) return;                    // legal[argmax([])] would raise; game is over
+    const int bi = argmax_policy(d, g, s.mv, mi.n, pol, lane);
+    const u32 mv = s.mv[bi];
+    __syncthreads();
+    if (lane == 0) moves_out[g] = (u16)mv;
+    if (push && d.game_result[g] == RESULT_NONE) game_push(d, g, b, mv, lane, s);
+}
+
+// ---- SelfPlayTree seam kernels -------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    if (lane == 0) { d.leaf_kind[g] = LEAF_NONE; d.path_len[g] = 0; }
+    if (d.game_result[g] != RESULT_NONE) {
+        if (lane == 0) { d.root_dead[g] = 1; d.n_nodes[g] = 0; d.root_visits[g] = 0; }
+        return;
+    }
+    Board b = d.cur[g];
+    const int p = d.ply[g];
+    MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+    __syncthreads();
+    init_edges(d, eb, 0, mi.n, s.mv, lane);
+    if (lane == 0) {
+        NodeMeta m;
+        m.edge0 = 0; m.nmoves = (u16)mi.n; m.nexp = 0; m.result = RESULT_NONE; m.has_s2 = 1;
+        m.parent = 0; m.parent_edge = -1;
+        d.meta[nb] = m;
+        d.nb2[nb] = b;
+        d.nh2[nb] = board_hash(b);
+        d.n_nodes[g] = 1;
+        d.edge_top[g] = mi.n;
+        d.root_visits[g] = 1;                // Tree.__init__: root.visits = 1
+        d.root_dead[g] = 0;
+        d.path_node[nb] = 0;
+    }
+    __syncthreads();
+    encode_position(d, g, b, 0, p, p, lane, s, planes);
+}
+
+__global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (d.root_dead[g]) return;
+    NodeMeta m = d.meta[(size_t)g * d.N];
+    gather_priors(d, g, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane);
+    if (lane == 0) d.counters[(size_t)g * CNT_N + CNT_EVALS] += 1;
+}
+
+// simulate + backprop (+ priors of the new node's future children) for the pending simulation
+__device__ inline void backup_pending(const Dev &d, int g, int lane, const float *pol2,
+                                      const float *val2)
+{
+    const int kind = d.leaf_kind[g];
+    if (kind == LEAF_NONE) return;
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    if (kind == LEAF_NEW_REPLY) { dev_error(d, DERR_STATE); return; }
+    const int leaf = d.leaf_node[g];
+    NodeMeta m = d.meta[nb + leaf];
+    double v;
+    unsigned long long evals = 0;
+    if (m.result != RESULT_NONE) {
+        v = (double)m.result;                          // state.get_result() (mctree.py:268)
+    } else {
+        v = (double)val2[g];                           // python float of the f32 value head
+        gather_priors(d, g, eb, m.edge0, m.nmoves, pol2, lane);
+        evals = 1;                                     // policy/value(S2)
+    }
+    if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
+    const int plen = d.path_len[g];
+    for (int l = lane; l < plen; l += 64) {
+        size_t e = eb + d.path_edge[nb + l];
+        d.e_visits[e] += 1;
+        d.e_value[e] = __dadd_rn(d.e_value[e], v);
+    }
+    if (lane == 0) {
+        d.root_visits[g] += 1;
+        d.leaf_kind[g] = LEAF_NONE;
+        unsigned long long *c = d.counters + (size_t)g * CNT_N;
+        c[CNT_SIMS] += 1;
+        c[CNT_DEPTH] += plen;
+        c[CNT_EVALS] += evals;
+        if (kind == LEAF_TERMINAL_HIT) c[CNT_TERMINAL] += 1;
+        else { c[CNT_NODES] += 1; c[CNT_BRANCH] += m.nmoves; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_backup(Dev d, const float *pol2, const float *val2)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (d.root_dead[g]) return;
+    backup_pending(d, g, lane, pol2, val2);
+}
+
+__global__ __launch_bounds__(64) void k_select_expand(Dev d, const float *pol2, const float *val2,
+                                                      void *planes1)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (d.root_dead[g]) return;
+    backup_pending(d, g, lane, pol2, val2);
+
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    const bool legacy = (d.flags & 1u) != 0;
+    const int p = d.ply[g];
+    int node = 0, level = 0;
+    for (;;) {
+        NodeMeta m = d.meta[nb + node];
+        const int edge0 = uni(m.edge0), nmoves = uni(m.nmoves), nexp = uni(m.nexp);
+        const int result = uni(m.result);
+        if (result != RESULT_NONE) {                                   // is_terminal_state
+            if (lane == 0) { d.leaf_kind[g] = LEAF_TERMINAL_HIT; d.leaf_node[g] = node; }
+            break;
+        }
+        if (nexp < nmoves) {                                           // not fully expanded
+            const int j = nmoves - 1 - nexp;                           // list.pop(): last first
+            const int edge = edge0 + j;
+            const u32 mv = d.e_move[eb + edge];
+            const int c = d.n_nodes[g];
+            if (c >= d.N || level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
+            if (lane == 0) {
+                d.meta[nb + node].nexp = (u16)(nexp + 1);
+                d.path_edge[nb + level] = edge;
+                d.path_node[nb + level + 1] = (u16)c;
+                d.n_nodes[g] = c + 1;
+            }
+            level++;
+            Board parent = d.nb2[nb + node];
+            Board s1 = apply_move(parent, mv);
+            __syncthreads();                                           // path_node visible
+            PosEval e = eval_position(d, g, s1, 2 * level - 1, p, p, lane, s);
+            NodeMeta cm;
+            cm.edge0 = 0; cm.nmoves = (u16)e.n; cm.nexp = 0; cm.result = (int8_t)e.result;
+            cm.has_s2 = 0; cm.parent = (u16)node; cm.parent_edge = edge;
+            if (lane == 0) {
+                d.nb1[nb + c] = e.b;
+                d.nh1[nb + c] = e.hash;
+                d.meta[nb + c] = cm;
+                d.leaf_node[g] = c;
+            }
+            if (e.result != RESULT_NONE) {                              // game ended on our move
+                if (lane == 0) {
+                    d.nb2[nb + c] = e.b;
+                    d.nh2[nb + c] = e.hash;
+                    d.e_child[eb + edge] = (u16)(c | CHILD_TERMINAL);
+                    d.leaf_kind[g] = LEAF_NEW_S1_OVER;
+                }
+            } else {
+                for (int i = lane; i < e.n; i += 64) d.s1_moves[(size_t)g * MAX_MOVES + i] = s.mv[i];
+                if (lane == 0) {
+                    d.e_child[eb + edge] = (u16)c;
+                    d.s1_n[g] = e.n;
+                    d.leaf_kind[g] = LEAF_NEW_REPLY;
+                }
+                __syncthreads();
+                encode_position(d, g, e.b, 2 * level - 1, p, p, lane, s, planes1);
+            }
+            break;
+        }
+        // ---- get_best_child (mctree.py:89-95): argmax of Q+U, first max in children order,
+        // i.e. the LARGEST legal index among equals
+        double best = -__builtin_inf();
+        int bj = -1;
+        for (int base = 0; base < nmoves; base += 64) {
+            const int j = base + lane;
+            if (j < nmoves) {
+                const size_t e = eb + edge0 + j;
+                const int n = d.e_visits[e];
+                const double w = d.e_value[e];
+                const float pr = d.e_prior[e];
+                const bool term = (d.e_child[e] & CHILD_TERMINAL) != 0;
+                const double den = (double)(1 + n);
+                const double q = __ddiv_rn(w, den);
+                const double sumv = term ? 0.0 : (double)(n - 1);
+                const double cp = legacy ? __dmul_rn(10.0, (double)pr)
+                                         : (double)__fmul_rn(10.0f, pr);
+                const double u = __dmul_rn(cp, __ddiv_rn(__dsqrt_rn(sumv), den));
+                const double sc = __dadd_rn(q, u);
+                if (bj < 0 || sc > best || (sc == best && j > bj)) { best = sc; bj = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ob = __shfl_xor(best, o);
+            const int oj = __shfl_xor(bj, o);
+            const bool take = oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj));
+            if (take) { best = ob; bj = oj; }
+        }
+        bj = uni(bj);
+        const int edge = edge0 + bj;
+        const int child = d.e_child[eb + edge] & CHILD_NONE;
+        if (level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
+        if (lane == 0) {
+            d.path_edge[nb + level] = edge;
+            d.path_node[nb + level + 1] = (u16)child;
+        }
+        level++;
+        node = uni(child);
+    }
+    if (lane == 0) d.path_len[g] = level;
+}
+
+__global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *planes2)
+{
+    __shared__ WaveLds s;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (d.root_dead[g] || d.leaf_kind[g] != LEAF_NEW_REPLY) return;
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    const int c = d.leaf_node[g], level = d.path_len[g], n1 = d.s1_n[g], p = d.ply[g];
+    Board s1 = d.nb1[nb + c];
+    // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
+    const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
+    const int bi = argmax_policy(d, g, mv1, n1, pol1, lane);
+    const u32 reply = mv1[bi];
+    Board s2 = apply_move(s1, reply);
+    PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);
+    const int edge0 = d.edge_top[g];
+    if (edge0 + e.n > d.ECAP) { dev_error(d, DERR_EDGE_POOL); return; }
+    init_edges(d, eb, edge0, e.n, s.mv, lane);
+    if (lane == 0) {
+        NodeMeta m = d.meta[nb + c];
+        m.edge0 = edge0; m.nmoves = (u16)e.n; m.nexp = 0; m.result = (int8_t)e.result; m.has_s2 = 1;
+        d.meta[nb + c] = m;
+        d.nb2[nb + c] = e.b;
+        d.nh2[nb + c] = e.hash;
+        d.n_reply[nb + c] = (u16)reply;
+        d.edge_top[g] = edge0 + e.n;
+        if (e.result != RESULT_NONE) d.e_child[eb + m.parent_edge] = (u16)(c | CHILD_TERMINAL);
+        d.leaf_kind[g] = LEAF_NEW_S2;
+    }
+    __syncthreads();
+    encode_position(d, g, e.b, 2 * level, p, p, lane, s, planes2);
+}
+
+__global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, int32_t *visits,
+                                                      double *values, float *priors, u16 *moves,
+                                                      u16 *replies, int32_t *root_visits)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    if (d.root_dead[g]) {
+        if (lane == 0) { nchild[g] = 0; root_visits[g] = 0; }
+        return;
+    }
+    NodeMeta m = d.meta[nb];
+    if (lane == 0) { nchild[g] = m.nexp; root_visits[g] = d.root_visits[g]; }
+    for (int k = lane; k < m.nexp; k += 64) {
+        const size_t e = eb + m.edge0 + (m.nmoves - 1 - k);      // children order = reverse legal
+        const size_t o = (size_t)g * MAX_MOVES + k;
+        const int c = d.e_child[e] & CHILD_NONE;
+        visits[o] = d.e_visits[e];
+        values[o] = d.e_value[e];
+        priors[o] = d.e_prior[e];
+        moves[o] = d.e_move[e];
+        replies[o] = d.meta[nb + c].has_s2 ? d.n_reply[nb + c] : NO_MOVE;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u16 *bm, u16 *am)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (lane != 0) return;
+    bm[g] = NO_MOVE; am[g] = NO_MOVE;
+    const int k = chosen[g];
+    if (k < 0 || d.root_dead[g]) return;
+    const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
+    NodeMeta m = d.meta[nb];
+    if (k >= m.nexp || d.leaf_kind[g] != LEAF_NONE) { dev_error(d, DERR_STATE); return; }
+    const size_t e = eb + m.edge0 + (m.nmoves - 1 - k);
+    const int c = d.e_child[e] & CHILD_NONE;
+    NodeMeta cm = d.meta[nb + c];
+    const int p = d.ply[g];
+    const int np = p + (cm.has_s2 ? 2 : 1);
+    if (np > d.MAXPLY) { dev_error(d, DERR_PLY_POOL); return; }
+    size_t hi = (size_t)g * HIST_RING + ((p + 1) & (HIST_RING - 1));
+    d.hist[hi] = d.nb1[nb + c];
+    d.hist_hash[hi] = d.nh1[nb + c];
+    d.rec_moves[(size_t)g * d.MAXPLY + p] = d.e_move[e];
+    bm[g] = d.e_move[e];
+    if (cm.has_s2) {
+        hi = (size_t)g * HIST_RING + ((p + 2) & (HIST_RING - 1));
+        d.hist[hi] = d.nb2[nb + c];
+        d.hist_hash[hi] = d.nh2[nb + c];
+        d.rec_moves[(size_t)g * d.MAXPLY + p + 1] = d.n_reply[nb + c];
+        am[g] = d.n_reply[nb + c];
+    }
+    d.cur[g] = d.nb2[nb + c];                 // node state (S1 copy when the game ended there)
+    d.ply[g] = np;
+    d.game_result[g] = cm.result;
+    d.root_dead[g] = 1;                       // the tree is consumed: fresh tree per move
+}
+
+}  // namespace crl

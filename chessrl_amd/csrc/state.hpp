@@ -1,0 +1,99 @@
+// state.hpp -- HBM layout of the lockstep self-play state (one context per GPU).
+//
+// Everything is structure-of-arrays, game-major, sized at crl_create and never
+// reallocated.  G games advance in lockstep; each owns a fresh search tree per
+// move (agentdistributed.py:61-63) of at most N = max_sims + 1 nodes, because
+// one simulation creates at most one node (mctree.py:231-257).
+//
+//   games   cur[G]                current position (== hist ring at ply)
+//           hist[G][256]          ring of the last 256 positions  (encoder history,
+//           hist_hash[G][256]     fivefold repetition; python-chess move stack)
+//           rec_moves[G][P]       the game record, u16 move ids (game.py:59-66)
+//   nodes   meta[G][N]            16-byte record: edge range, expansion cursor, result
+//           nb1/nb2[G][N]         S1 (after our move) / S2 (after the stored reply)
+//           nh1/nh2[G][N]         transposition-key filter hashes of S1 / S2
+//   edges   e_*[G][ECAP]          one slot per LEGAL MOVE of a node, in python-chess
+//                                 order: child's visits (i32), value sum (f64), prior
+//                                 (f32), move (u16), child node id | terminal<<15.
+//                                 A node's children stats are contiguous, so the PUCT
+//                                 scan of get_best_child (mctree.py:89-95) is one
+//                                 coalesced 64-lane read per array.
+//   step    path_*[G][N]          the selection path of the pending simulation
+#pragma once
+#include "board.hpp"
+
+namespace crl {
+
+constexpr int HIST_RING = 256;
+constexpr int MAX_MOVES = 256;
+constexpr int MAX_BRANCH = 218;      // most legal moves in any reachable position
+constexpr int N_LABELS = 1968;
+constexpr int PLANES = 128;
+constexpr u16 CHILD_NONE = 0x7FFF;
+constexpr u16 CHILD_TERMINAL = 0x8000;
+
+enum LeafKind : uint8_t {
+    LEAF_NONE = 0,          // no simulation pending
+    LEAF_TERMINAL_HIT = 1,  // selection ended on an existing terminal node
+    LEAF_NEW_S1_OVER = 2,   // new node whose game ended on our move (state = S1)
+    LEAF_NEW_REPLY = 3,     // new node waiting for the opponent's reply (needs policy(S1))
+    LEAF_NEW_S2 = 4         // new node complete (state = S2)
+};
+
+struct __attribute__((aligned(16))) NodeMeta {
+    int32_t edge0;          // first edge slot (game-relative)
+    u16 nmoves;             // b = number of legal moves = number of edge slots
+    u16 nexp;               // children created so far; next expansion is legal index b-1-nexp
+    int8_t result;          // Game.get_result() of the node state; RESULT_NONE = running
+    uint8_t has_s2;         // state is S2 (1) or S1 (0, game ended on our move)
+    u16 parent;             // parent node id
+    int32_t parent_edge;    // edge slot in the parent (game-relative), -1 for the root
+};
+static_assert(sizeof(NodeMeta) == 16, "NodeMeta must be 16 bytes");
+
+enum Counter { CNT_SIMS = 0, CNT_NODES, CNT_DEPTH, CNT_BRANCH, CNT_EVALS, CNT_TERMINAL, CNT_N };
+
+struct Dev {
+    int G, N, ECAP, MAXPLY;
+    u32 flags;
+    // games
+    Board *cur;
+    int32_t *ply;
+    Board *hist;
+    u64 *hist_hash;
+    u16 *rec_moves;
+    int8_t *game_result;
+    // tree
+    int32_t *n_nodes, *edge_top, *root_visits;
+    uint8_t *root_dead;
+    NodeMeta *meta;
+    Board *nb1, *nb2;
+    u64 *nh1, *nh2;
+    u16 *n_reply;
+    u16 *e_move, *e_child;
+    int32_t *e_visits;
+    float *e_prior;
+    double *e_value;
+    // pending simulation
+    int32_t *path_len, *path_edge, *leaf_node;
+    u16 *path_node;
+    uint8_t *leaf_kind;
+    u16 *s1_moves;
+    int32_t *s1_n;
+    // misc
+    const u16 *lut;                    // [5][4096] move -> label index (0xFFFF = none)
+    unsigned long long *counters;      // [G][CNT_N]
+    int32_t *err;                      // sticky device error code
+};
+
+enum DevErr { DERR_NONE = 0, DERR_NODE_POOL = 1, DERR_EDGE_POOL = 2, DERR_PLY_POOL = 3,
+              DERR_STATE = 4, DERR_BRANCH = 5, DERR_LABEL = 6 };
+
+__device__ inline int label_of(const Dev &d, u32 mv)
+{
+    u32 p = (mv >> 12) & 7;
+    u32 slot = p ? 6 - p : 0;          // Q,R,B,N -> 1,2,3,4
+    return d.lut[slot * 4096 + (mv & 4095)];
+}
+
+}  // namespace crl

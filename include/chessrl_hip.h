@@ -1,0 +1,144 @@
+/*
+ * chessrl_hip.h -- C-ABI of libchessrl_hip.so, the MI355X (gfx950) drop-in for
+ * the self-play MCTS simulation loop of AIRLegend/ChessRL.
+ *
+ * The reference is pure Python and defines no FFI; its seams for this path are
+ * duck-typed Python methods.  Each entry point below
+ * names the reference method(s) it replaces (paths relative to
+ * /root/reference/src/chessrl/).  The Python host mirror (chessrl_amd/game.py,
+ * agent.py, mctree.py, selfplay.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, no torch types; every call returns 0
+ * on success or a negative crl_status and records a message retrievable with
+ * crl_last_error(); one context per GPU, not thread-safe per context; "dev_"
+ * pointers are device memory (e.g. torch.Tensor.data_ptr()), all others are
+ * caller-owned host memory; kernels are enqueued on the stream given to
+ * crl_set_stream() (torch's current stream) so they order with the tower and
+ * can be captured into a hipGraph; calls that fill host buffers synchronise
+ * that stream themselves.  G = max_games given to crl_create.
+ */
+#ifndef CHESSRL_HIP_H
+#define CHESSRL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One chess position, 64 bytes.  Squares a1 = 0 ... h8 = 63 (python-chess). */
+typedef struct crl_board {
+    uint64_t bb[6];   /* pawns, knights, bishops, rooks, queens, kings (both colours) */
+    uint64_t white;   /* squares occupied by white pieces                              */
+    uint32_t state;   /* bit 0      side to move (1 = white)
+                         bits 1-4   castling rights: WK(h1) WQ(a1) BK(h8) BQ(a8)
+                         bits 5-11  en-passant square, 64 = none (set on EVERY double push)
+                         bits 12-19 halfmove clock (saturates at 255)
+                         bit 20     a legal en-passant capture exists (derived; recomputed
+                                    by the library, ignored on input)                   */
+    uint32_t pad;
+} crl_board;
+
+/* A move is a uint16: from | to << 6 | promo << 12, promo in {0, 2=N, 3=B, 4=R, 5=Q};
+ * castling is the king move (e1g1), as python-chess prints it.  0xFFFF = "no move". */
+#define CRL_NO_MOVE 0xFFFFu
+#define CRL_MAX_MOVES 256      /* row stride of every per-position move list           */
+#define CRL_N_LABELS 1968      /* netencoder.get_uci_labels(), netencoder.py:94-134     */
+#define CRL_PLANES 128         /* 127 reference planes + 1 zero pad, fp16 NHWC          */
+#define CRL_RESULT_NONE 2      /* Game.get_result() is None                             */
+
+typedef enum crl_status {
+    CRL_OK = 0,
+    CRL_ERR_ARG = -1,          /* bad argument                                          */
+    CRL_ERR_HIP = -2,          /* HIP runtime failure (message has the hipError string) */
+    CRL_ERR_CAPACITY = -3,     /* a device pool overflowed (nodes / edges / plies)      */
+    CRL_ERR_STATE = -4         /* call not valid in the current search state            */
+} crl_status;
+
+/* crl_create flags */
+#define CRL_FLAG_NUMPY_LEGACY 1u  /* PUCT: 10*prior evaluated in float64 (numpy 1.x scalar
+                                     promotion, the reference's pinned numpy==1.17.2);
+                                     default is numpy>=2 (product rounded to float32).  */
+
+typedef struct crl_ctx crl_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+int  crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_plies,
+                uint32_t flags);
+void crl_destroy(crl_ctx *ctx);
+int  crl_set_stream(crl_ctx *ctx, void *hip_stream);
+int  crl_sync(crl_ctx *ctx);                 /* wait for the stream; report device errors */
+const char *crl_last_error(crl_ctx *ctx);    /* ctx may be NULL for crl_create failures   */
+int  crl_max_games(crl_ctx *ctx);
+int  crl_max_sims(crl_ctx *ctx);
+
+/* netencoder.get_uci_labels (netencoder.py:94-134): move id of each of the 1968 labels */
+int  crl_uci_label_moves(uint16_t *moves_out /*1968*/);
+
+/* ---- Game seam (game.py) ------------------------------------------------------------ */
+/* Game.__init__/reset (game.py:17-26,82-83): slots with mask[g] != 0 (NULL = all)
+ * restart from the standard position with an empty move stack. */
+int  crl_reset_games(crl_ctx *ctx, const uint8_t *mask);
+/* Game(board=...) / set_fen (game.py:17-21,71-72): slots 0..n-1 take `boards` with an
+ * EMPTY move stack (tests: arbitrary positions). */
+int  crl_set_positions(crl_ctx *ctx, const crl_board *boards, int n);
+int  crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n);
+/* Game.get_legal_moves (game.py:43-57): python-chess generation order. */
+int  crl_legal_moves(crl_ctx *ctx, uint16_t *moves /*G x 256*/, int32_t *counts /*G*/);
+/* Game.move (game.py:28-41): applied iff in the legal list; ok[g] = 1/0; CRL_NO_MOVE skips. */
+int  crl_push_moves(crl_ctx *ctx, const uint16_t *moves /*G*/, uint8_t *ok /*G*/);
+/* Game.get_result (game.py:92-109): 1 / -1 / 0, CRL_RESULT_NONE while running. */
+int  crl_results(crl_ctx *ctx, int8_t *result /*G*/);
+/* len(Game) and Game.get_history()['moves'] (game.py:59-66,111-112). */
+int  crl_records(crl_ctx *ctx, uint16_t *moves /*G x max_plies or NULL*/, int32_t *plies /*G*/,
+                 int8_t *result /*G or NULL*/);
+
+/* ---- encoder seam (netencoder.py) ------------------------------------------------------ */
+/* netencoder.get_game_state (netencoder.py:72-91) for every slot: fp16 NHWC
+ * [G][8][8][128] (row 0 = rank 8, col 0 = file a; channel 127 is a zero pad). */
+int  crl_encode(crl_ctx *ctx, void *dev_planes_f16);
+
+/* ---- Agent seam (agentdistributed.py) ----------------------------------------------- */
+/* AgentDistributed.best_move(real_game=True) (agentdistributed.py:56-58): per slot with
+ * mask[g] != 0 (NULL = all): legal[argmax(policy[label(m)] for m in legal)], first max.
+ * dev_policy_f32 is [G][1968].  If push != 0 the move is also played (selfplay.py:68-70).
+ * moves_out (host, may be NULL) receives the chosen move ids (CRL_NO_MOVE if game over). */
+int  crl_greedy_moves(crl_ctx *ctx, const void *dev_policy_f32, const uint8_t *mask, int push,
+                      uint16_t *moves_out);
+
+/* ---- SelfPlayTree seam (mctree.py), lockstep over all slots, threads=1 semantics -------- */
+/* Tree.__init__ (mctree.py:105-111): fresh tree per slot, root = current game, visits 1.
+ * Finished games get an inert root.  Also encodes every root into dev_planes_f16 (the
+ * reference evaluates the root's policy in _update_prior, mctree.py:298-303). */
+int  crl_search_begin(crl_ctx *ctx, void *dev_planes_f16);
+/* Root part of _update_prior: priors of the root's children from the tower's policy. */
+int  crl_search_root_priors(crl_ctx *ctx, const void *dev_policy_f32);
+/* First half of explore_tree (mctree.py:200-257): [backprop of the previous simulation
+ * (mctree.py:278-296) if one is pending, using the S2 outputs], then select to a leaf,
+ * pop the last unexpanded move, play it (S1) and encode S1 where the opponent must reply.
+ * dev_policy_s2/dev_value_s2 may be NULL only when no simulation is pending. */
+int  crl_sim_select_expand(crl_ctx *ctx, const void *dev_policy_s2_f32,
+                           const void *dev_value_s2_f32, void *dev_planes_s1_f16);
+/* Second half of expand (mctree.py:244-250): opponent's greedy reply from policy(S1),
+ * S2 = S1 + reply, Node(S2) with its legal moves, encode S2. */
+int  crl_sim_reply(crl_ctx *ctx, const void *dev_policy_s1_f32, void *dev_planes_s2_f16);
+/* simulate + backprop + child priors (mctree.py:259-303) for the pending simulation. */
+int  crl_sim_backup(crl_ctx *ctx, const void *dev_policy_s2_f32, const void *dev_value_s2_f32);
+/* [c.visits for c in root.children] etc., CHILDREN order (= reverse legal order);
+ * rows of 256; any output may be NULL. */
+int  crl_root_children(crl_ctx *ctx, int32_t *nchild /*G*/, int32_t *visits, double *values,
+                       float *priors, uint16_t *moves, uint16_t *replies, int32_t *root_visits);
+/* selfplay.play_game's two pushes (selfplay.py:77-78) for the chosen root child per slot
+ * (children-order index, -1 = leave the slot alone).  bm/am (host, may be NULL) get our
+ * move and the stored reply (CRL_NO_MOVE when the game ended on our move). */
+int  crl_advance(crl_ctx *ctx, const int32_t *chosen /*G*/, uint16_t *bm, uint16_t *am);
+/* Device-side counters since crl_create: [0] simulations run, [1] nodes created,
+ * [2] sum of selection depth (edges), [3] sum of legal moves over created nodes,
+ * [4] tower evaluations consumed, [5] terminal leaves hit. */
+int  crl_counters(crl_ctx *ctx, uint64_t *out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHESSRL_HIP_H */

@@ -1,0 +1,166 @@
+"""GPU parity: bitboard move generation / push / result kernels vs the CPU oracle.
+
+Bar: bit-exact -- legal-move SET and ORDER, resulting positions (all state bits,
+including the derived legal-en-passant bit), Game.move's bool and
+Game.get_result.  Everything goes through the C-ABI (chessrl_amd._lib.Context).
+"""
+import numpy as np
+import pytest
+
+from tests.util import PERFT_FENS, OracleGame, board_from_fen, board_to_array, oracle_row
+
+pytestmark = pytest.mark.gpu
+
+START_ORDER = ["g1h3", "g1f3", "b1c3", "b1a3", "h2h3", "g2g3", "f2f3", "e2e3", "d2d3", "c2c3",
+               "b2b3", "a2a3", "h2h4", "g2g4", "f2f4", "e2e4", "d2d4", "c2c4", "b2b4", "a2a4"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from chessrl_amd._lib import Context
+    c = Context(max_games=256, max_sims=8, max_plies=1024)
+    yield c
+    c.close()
+
+
+def _res(game):
+    r = game.get_result()
+    return 2 if r is None else r
+
+
+def test_start_position_order(ctx):
+    from oracle.chess_oracle import move_to_uci
+    ctx.reset_games()
+    moves, counts = ctx.legal_moves()
+    assert (counts == 20).all()
+    assert [move_to_uci(m) for m in moves[0, :20]] == START_ORDER   # python-chess README listing
+    assert (ctx.results() == 2).all()
+
+
+def test_known_positions_and_children(ctx):
+    """perft-suite positions: moves of the position and of every child (depth 2)."""
+    roots = [OracleGame(board=board_from_fen(f)) for f in PERFT_FENS.values()]
+    games = list(roots)
+    for r in roots:
+        for m in r.get_legal_moves():
+            c = r.get_copy()
+            assert c.move(m)
+            games.append(c)
+    for lo in range(0, len(games), ctx.G):
+        chunk = games[lo:lo + ctx.G]
+        # children carry history in the oracle; on the device they are set up bare, which only
+        # matters for repetition (not reachable at depth 1)
+        ctx.set_positions(np.stack([oracle_row(g) for g in chunk]))
+        moves, counts = ctx.legal_moves()
+        res = ctx.results()
+        pos = ctx.get_positions(len(chunk))
+        for i, g in enumerate(chunk):
+            exp = g.legal_move_ids()
+            assert counts[i] == len(exp), (i, g.get_fen())
+            assert list(moves[i, :counts[i]]) == exp, (i, g.get_fen())
+            assert res[i] == _res(g)
+            assert (pos[i] == oracle_row(g)).all()
+
+
+def test_random_games_lockstep(ctx):
+    """256 seeded random games, 260 plies: every ply compares list, order, state, result."""
+    rng = np.random.default_rng(20261002)
+    G = ctx.G
+    ctx.reset_games()
+    games = [OracleGame() for _ in range(G)]
+    n_checked = 0
+    for ply in range(260):
+        moves, counts = ctx.legal_moves()
+        res = ctx.results()
+        pos = ctx.get_positions()
+        push = np.full(G, 0xFFFF, dtype=np.uint16)
+        for i, g in enumerate(games):
+            exp = g.legal_move_ids()
+            assert counts[i] == len(exp), (ply, i)
+            assert list(moves[i, :counts[i]]) == exp, (ply, i)
+            assert res[i] == _res(g), (ply, i)
+            assert (pos[i] == oracle_row(g)).all(), (ply, i)
+            n_checked += len(exp)
+            if exp and res[i] == 2:
+                # bias towards captures/pawn moves being rare so that clocks and repetitions grow
+                push[i] = exp[int(rng.integers(len(exp)))]
+        ok = ctx.push_moves(push)
+        for i, g in enumerate(games):
+            if push[i] != 0xFFFF:
+                from oracle.chess_oracle import move_to_uci
+                assert ok[i] == 1
+                assert g.move(move_to_uci(push[i]))
+            else:
+                assert ok[i] == 0
+    assert n_checked > 500000
+    _, plies, _ = ctx.records(with_moves=False)
+    assert list(plies) == [len(g) for g in games]
+
+
+def test_illegal_and_null_moves_are_refused(ctx):
+    from oracle.chess_oracle import uci_to_move
+    ctx.reset_games()
+    push = np.full(ctx.G, 0xFFFF, dtype=np.uint16)
+    push[0] = uci_to_move("e2e5")        # not legal
+    push[1] = uci_to_move("e7e5")        # black's move
+    push[2] = uci_to_move("e2e4")        # legal
+    push[3] = uci_to_move("e1g1")        # castling not available
+    ok = ctx.push_moves(push)
+    assert list(ok[:5]) == [0, 0, 1, 0, 0]
+    _, plies, _ = ctx.records(with_moves=False)
+    assert list(plies[:5]) == [0, 0, 1, 0, 0]
+
+
+def _shuffle(games_dev, games_or, seq, reps):
+    from oracle.chess_oracle import uci_to_move
+    for _ in range(reps):
+        for u in seq:
+            push = np.full(games_dev.G, 0xFFFF, dtype=np.uint16)
+            push[0] = uci_to_move(u)
+            assert games_dev.push_moves(push)[0] == 1
+            assert games_or.move(u)
+            assert games_dev.results()[0] == _res(games_or)
+
+
+def test_fivefold_repetition(ctx):
+    ctx.reset_games()
+    g = OracleGame()
+    _shuffle(ctx, g, ["g1f3", "g8f6", "f3g1", "f6g8"], 4)
+    assert g.get_result() == 0 and g.repetitions() == 5
+    assert ctx.results()[0] == 0
+
+
+def test_repetition_respects_castling_rights_and_ep(ctx):
+    """Positions that differ only in castling rights / legal ep are different keys."""
+    from oracle.chess_oracle import uci_to_move
+    ctx.reset_games()
+    g = OracleGame()
+    for u in ["e2e4", "e7e5", "e1e2", "e8e7", "e2e1", "e7e8"]:      # rights lost on the way
+        push = np.full(ctx.G, 0xFFFF, dtype=np.uint16)
+        push[0] = uci_to_move(u)
+        assert ctx.push_moves(push)[0] == 1 and g.move(u)
+    _shuffle(ctx, g, ["g1f3", "g8f6", "f3g1", "f6g8"], 4)
+    assert (ctx.get_positions(1)[0] == oracle_row(g)).all()
+    assert ctx.results()[0] == _res(g)
+
+
+def test_fifty_move_claim_and_insufficient_material(ctx):
+    from oracle.chess_oracle import uci_to_move
+    fens = ["8/8/8/4k3/8/8/4K3/7R w - - 98 80",      # two quiet moves reach clock 100
+            "8/8/8/4k3/8/8/4K3/7B w - - 0 1",        # K+B vs K: insufficient
+            "8/8/8/4k3/8/8/4K3/6NN w - - 0 1",       # K+N+N vs K: sufficient
+            "8/8/4b3/4k3/8/8/4K3/5B2 w - - 0 1",     # same-coloured bishops (f1 light? e6 light)
+            "7k/5Q2/6K1/8/8/8/8/8 b - - 0 1",        # stalemate
+            "7k/6Q1/6K1/8/8/8/8/8 b - - 0 1"]        # checkmate, white wins
+    games = [OracleGame(board=board_from_fen(f)) for f in fens]
+    ctx.set_positions(np.stack([board_to_array(board_from_fen(f)) for f in fens]))
+    res = ctx.results()
+    for i, g in enumerate(games):
+        assert res[i] == _res(g), fens[i]
+    assert res[4] == 0 and res[5] == 1
+    for u in ["h1h2", "e5e6"]:
+        push = np.full(ctx.G, 0xFFFF, dtype=np.uint16)
+        push[0] = uci_to_move(u)
+        assert ctx.push_moves(push)[0] == 1 and games[0].move(u)
+        assert ctx.results()[0] == _res(games[0])
+    assert ctx.results()[0] == 0
