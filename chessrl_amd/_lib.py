@@ -27,7 +27,7 @@ FLAG_NUMPY_LEGACY = 1
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
-    "crl_max_sims", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
+    "crl_max_sims", "crl_set_window", "crl_copy_game", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
@@ -82,6 +82,8 @@ def lib():
     L.crl_last_error.restype = ctypes.c_char_p
     L.crl_max_games.argtypes = [vp]
     L.crl_max_sims.argtypes = [vp]
+    L.crl_set_window.argtypes = [vp, i32, i32]
+    L.crl_copy_game.argtypes = [vp, i32, i32]
     L.crl_uci_label_moves.argtypes = [vp]
     L.crl_reset_games.argtypes = [vp, vp]
     L.crl_set_positions.argtypes = [vp, vp, i32]
@@ -132,6 +134,7 @@ class Context(object):
             self._h = None
             raise HipLibraryError("crl_create failed (%d): %s" % (rc, (msg or b"").decode()))
         self.G, self.max_sims, self.max_plies, self.device = max_games, max_sims, max_plies, device
+        self.n_slots = max_games
 
     def close(self):
         if getattr(self, "_h", None):
@@ -151,6 +154,14 @@ class Context(object):
 
     def set_stream(self, stream_ptr):
         self._ck(self._L.crl_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "crl_set_stream")
+
+    def set_window(self, first, count):
+        """Later calls act on slots [first, first+count); arrays become `count` rows."""
+        self._ck(self._L.crl_set_window(self._h, first, count), "crl_set_window")
+        self.G = count
+
+    def copy_game(self, dst, src):
+        self._ck(self._L.crl_copy_game(self._h, dst, src), "crl_copy_game")
 
     def sync(self):
         self._ck(self._L.crl_sync(self._h), "crl_sync")

@@ -18,6 +18,7 @@ static thread_local std::string g_create_error;
 
 struct crl_ctx {
     int device = 0;
+    int W = 0;                    // slots in the active window [d.g0, d.g0 + W)
     hipStream_t stream = nullptr;
     Dev d{};
     std::vector<void *> allocs;
@@ -130,7 +131,7 @@ static int check_dev_error(crl_ctx *ctx)
 
 #define LAUNCH(ctx, kern, ...)                                                          \
     do {                                                                                \
-        hipLaunchKernelGGL(kern, dim3((ctx)->d.G), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, dim3((ctx)->W), dim3(64), 0, (ctx)->stream, __VA_ARGS__); \
         HIP_TRY(ctx, hipGetLastError());                                                \
     } while (0)
 
@@ -154,6 +155,8 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     d.ECAP = d.N * MAX_BRANCH;
     d.MAXPLY = max_plies;
     d.flags = flags;
+    d.g0 = 0;
+    ctx->W = max_games;
     const size_t G = d.G, GN = G * d.N, GE = G * (size_t)d.ECAP;
     bool ok = true;
 #define A(ptr, count) ok = ok && (dalloc(ctx, &(ptr), (count)) == hipSuccess)
@@ -223,6 +226,27 @@ int crl_sync(crl_ctx *ctx)
     return check_dev_error(ctx);
 }
 
+int crl_set_window(crl_ctx *ctx, int first, int count)
+{
+    if (!ctx || first < 0 || count < 1 || first + count > ctx->d.G)
+        return fail(ctx, CRL_ERR_ARG, "crl_set_window: bad slot range");
+    ctx->d.g0 = first;
+    ctx->W = count;
+    return CRL_OK;
+}
+
+int crl_copy_game(crl_ctx *ctx, int dst, int src)
+{
+    if (!ctx || dst < 0 || src < 0 || dst >= ctx->d.G || src >= ctx->d.G)
+        return fail(ctx, CRL_ERR_ARG, "crl_copy_game: bad slot");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (dst != src) {
+        hipLaunchKernelGGL(k_copy_game, dim3(1), dim3(64), 0, ctx->stream, ctx->d, dst, src);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return CRL_OK;
+}
+
 const char *crl_last_error(crl_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 int crl_max_games(crl_ctx *ctx) { return ctx ? ctx->d.G : CRL_ERR_ARG; }
 int crl_max_sims(crl_ctx *ctx) { return ctx ? ctx->d.N - 1 : CRL_ERR_ARG; }
@@ -244,17 +268,17 @@ int crl_reset_games(crl_ctx *ctx, const uint8_t *mask)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint8_t *dm = nullptr;
     if (mask) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->d.G, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->W, hipMemcpyHostToDevice, ctx->stream));
         dm = ctx->t_u8;
     }
-    LAUNCH(ctx, k_set_positions, ctx->d, (const Board *)nullptr, dm, ctx->d.G, 1);
+    LAUNCH(ctx, k_set_positions, ctx->d, (const Board *)nullptr, dm, ctx->W, 1);
     if (mask) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host mask may be freed by caller
     return CRL_OK;
 }
 
 int crl_set_positions(crl_ctx *ctx, const crl_board *boards, int n)
 {
-    if (!ctx || !boards || n < 0 || n > ctx->d.G) return fail(ctx, CRL_ERR_ARG, "crl_set_positions: bad argument");
+    if (!ctx || !boards || n < 0 || n > ctx->W) return fail(ctx, CRL_ERR_ARG, "crl_set_positions: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t_boards, boards, (size_t)n * sizeof(Board), hipMemcpyHostToDevice, ctx->stream));
     LAUNCH(ctx, k_set_positions, ctx->d, (const Board *)ctx->t_boards, (const uint8_t *)nullptr, n, 0);
@@ -264,9 +288,9 @@ int crl_set_positions(crl_ctx *ctx, const crl_board *boards, int n)
 
 int crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n)
 {
-    if (!ctx || !boards_out || n < 0 || n > ctx->d.G) return fail(ctx, CRL_ERR_ARG, "crl_get_positions: bad argument");
+    if (!ctx || !boards_out || n < 0 || n > ctx->W) return fail(ctx, CRL_ERR_ARG, "crl_get_positions: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(boards_out, ctx->d.cur, (size_t)n * sizeof(Board), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(boards_out, ctx->d.cur + ctx->d.g0, (size_t)n * sizeof(Board), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CRL_OK;
 }
@@ -275,7 +299,7 @@ int crl_legal_moves(crl_ctx *ctx, uint16_t *moves, int32_t *counts)
 {
     if (!ctx || !moves || !counts) return fail(ctx, CRL_ERR_ARG, "crl_legal_moves: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t G = ctx->d.G;
+    const size_t G = ctx->W;
     LAUNCH(ctx, k_legal_moves, ctx->d, ctx->t_moves, ctx->t_i32b);
     HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->t_moves, G * MAX_MOVES * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->t_i32b, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -286,7 +310,7 @@ int crl_push_moves(crl_ctx *ctx, const uint16_t *moves, uint8_t *ok)
 {
     if (!ctx || !moves || !ok) return fail(ctx, CRL_ERR_ARG, "crl_push_moves: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t G = ctx->d.G;
+    const size_t G = ctx->W;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u16a, moves, G * sizeof(u16), hipMemcpyHostToDevice, ctx->stream));
     LAUNCH(ctx, k_push, ctx->d, (const u16 *)ctx->t_u16a, ctx->t_u8);
     HIP_TRY(ctx, hipMemcpyAsync(ok, ctx->t_u8, G, hipMemcpyDeviceToHost, ctx->stream));
@@ -297,7 +321,7 @@ int crl_results(crl_ctx *ctx, int8_t *result)
 {
     if (!ctx || !result) return fail(ctx, CRL_ERR_ARG, "crl_results: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result, ctx->d.G, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result + ctx->d.g0, ctx->W, hipMemcpyDeviceToHost, ctx->stream));
     return check_dev_error(ctx);
 }
 
@@ -305,12 +329,12 @@ int crl_records(crl_ctx *ctx, uint16_t *moves, int32_t *plies, int8_t *result)
 {
     if (!ctx || !plies) return fail(ctx, CRL_ERR_ARG, "crl_records: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t G = ctx->d.G;
+    const size_t G = ctx->W;
     if (moves)
-        HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->d.rec_moves, G * ctx->d.MAXPLY * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->d.ply, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->d.rec_moves + (size_t)ctx->d.g0 * ctx->d.MAXPLY, G * ctx->d.MAXPLY * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->d.ply + ctx->d.g0, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (result)
-        HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result, G, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result + ctx->d.g0, G, hipMemcpyDeviceToHost, ctx->stream));
     return check_dev_error(ctx);
 }
 
@@ -328,12 +352,12 @@ int crl_greedy_moves(crl_ctx *ctx, const void *dev_policy_f32, const uint8_t *ma
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint8_t *dm = nullptr;
     if (mask) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->d.G, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->t_u8, mask, ctx->W, hipMemcpyHostToDevice, ctx->stream));
         dm = ctx->t_u8;
     }
     LAUNCH(ctx, k_greedy, ctx->d, (const float *)dev_policy_f32, dm, push, ctx->t_u16a);
     if (moves_out)
-        HIP_TRY(ctx, hipMemcpyAsync(moves_out, ctx->t_u16a, (size_t)ctx->d.G * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(moves_out, ctx->t_u16a, (size_t)ctx->W * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
     if (mask || moves_out) return check_dev_error(ctx);
     return CRL_OK;
 }
@@ -386,7 +410,7 @@ int crl_root_children(crl_ctx *ctx, int32_t *nchild, int32_t *visits, double *va
 {
     if (!ctx) return CRL_ERR_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t G = ctx->d.G, R = G * MAX_MOVES;
+    const size_t G = ctx->W, R = G * MAX_MOVES;
     LAUNCH(ctx, k_root_children, ctx->d, ctx->t_i32b, ctx->t_i32a, ctx->t_f64, ctx->t_f32, ctx->t_moves,
            ctx->t_moves2, ctx->t_i32c);
     hipStream_t s = ctx->stream;
@@ -404,7 +428,7 @@ int crl_advance(crl_ctx *ctx, const int32_t *chosen, uint16_t *bm, uint16_t *am)
 {
     if (!ctx || !chosen) return fail(ctx, CRL_ERR_ARG, "crl_advance: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t G = ctx->d.G;
+    const size_t G = ctx->W;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->t_i32b, chosen, G * 4, hipMemcpyHostToDevice, ctx->stream));
     LAUNCH(ctx, k_advance, ctx->d, (const int32_t *)ctx->t_i32b, ctx->t_u16a, ctx->t_u16b);
     if (bm) HIP_TRY(ctx, hipMemcpyAsync(bm, ctx->t_u16a, G * 2, hipMemcpyDeviceToHost, ctx->stream));

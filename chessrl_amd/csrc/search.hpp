@@ -108,7 +108,7 @@ __device__ inline PosEval eval_position(const Dev &d, int g, Board b, int tp, in
 // Lane l always owns channel group l&15, so its 8 plane bitboards stay in registers; each of the
 // 16 store iterations writes one contiguous 1 KiB per wave.
 __device__ inline void encode_position(const Dev &d, int g, const Board &b, int tp, int ply0,
-                                       int ring_top, int lane, WaveLds &s, void *planes_out)
+                                       int ring_top, int lane, WaveLds &s, void *planes_out, int row)
 {
     bool valid = false;
     if (lane < 9) {
@@ -143,7 +143,7 @@ __device__ inline void encode_position(const Dev &d, int g, const Board &b, int 
     u64 p8[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) p8[k] = s.pl[cg * 8 + k];
-    uint4 *out = (uint4 *)planes_out + (size_t)g * (64 * PLANES * 2 / 16);
+    uint4 *out = (uint4 *)planes_out + (size_t)row * (64 * PLANES * 2 / 16);
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const int sq = (t * 4 + (lane >> 4)) ^ 56;
@@ -175,19 +175,19 @@ __device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, con
     }
 }
 
-__device__ inline void gather_priors(const Dev &d, int g, size_t eb, int edge0, int n,
+__device__ inline void gather_priors(const Dev &d, int row, size_t eb, int edge0, int n,
                                      const float *pol, int lane)
 {
     for (int j = lane; j < n; j += 64) {
         size_t e = eb + edge0 + j;
         int lab = label_of(d, d.e_move[e]);
         if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
-        d.e_prior[e] = pol[(size_t)g * N_LABELS + lab];
+        d.e_prior[e] = pol[(size_t)row * N_LABELS + lab];
     }
 }
 
 // index of the first maximum of policy[label(m)] over the n moves in mv (np.argmax)
-__device__ inline int argmax_policy(const Dev &d, int g, const u16 *mv, int n, const float *pol,
+__device__ inline int argmax_policy(const Dev &d, int row, const u16 *mv, int n, const float *pol,
                                     int lane)
 {
     float best = -__builtin_inff();
@@ -197,7 +197,7 @@ __device__ inline int argmax_policy(const Dev &d, int g, const u16 *mv, int n, c
         if (i < n) {
             int lab = label_of(d, mv[i]);
             if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
-            float p = pol[(size_t)g * N_LABELS + lab];
+            float p = pol[(size_t)row * N_LABELS + lab];
             if (p > best || bi == 0x7FFFFFFF) { best = p; bi = i; }
         }
     }
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64) void k_set_positions(Dev d, const Board *in, co
                                                       int n, int use_start)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (g >= n || (mask && !mask[g])) return;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    if (r >= n || (mask && !mask[r])) return;
     Board b;
     if (use_start) {
         b.bb[PAWN] = 0x00FF00000000FF00ull; b.bb[KNIGHT] = 0x4200000000000042ull;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_set_positions(Dev d, const Board *in, co
         b.state = mk_state(1, 15, NO_EP, 0, 0);
         b.pad = 0;
     } else {
-        b = in[g];
+        b = in[r];
         b.state &= 0xFFFFFu;
         b.pad = 0;
     }
@@ -267,20 +267,20 @@ __global__ __launch_bounds__(64) void k_set_positions(Dev d, const Board *in, co
 __global__ __launch_bounds__(64) void k_legal_moves(Dev d, u16 *moves, int32_t *counts)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     Board b = d.cur[g];
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
-    for (int j = lane; j < mi.n; j += 64) moves[(size_t)g * MAX_MOVES + j] = s.mv[j];
-    if (lane == 0) counts[g] = mi.n;
+    for (int j = lane; j < mi.n; j += 64) moves[(size_t)r * MAX_MOVES + j] = s.mv[j];
+    if (lane == 0) counts[r] = mi.n;
 }
 
 __global__ __launch_bounds__(64) void k_push(Dev d, const u16 *moves, uint8_t *ok)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
-    const u32 mv = moves[g];
-    if (mv == NO_MOVE) { if (lane == 0) ok[g] = 0; return; }
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    const u32 mv = moves[r];
+    if (mv == NO_MOVE) { if (lane == 0) ok[r] = 0; return; }
     Board b = d.cur[g];
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
@@ -288,42 +288,62 @@ __global__ __launch_bounds__(64) void k_push(Dev d, const u16 *moves, uint8_t *o
     for (int j = lane; j < mi.n; j += 64) found = found || s.mv[j] == mv;
     const bool legal = __ballot(found) != 0;
     __syncthreads();
-    if (lane == 0) ok[g] = legal ? 1 : 0;
+    if (lane == 0) ok[r] = legal ? 1 : 0;
     if (legal) game_push(d, g, b, mv, lane, s);
 }
 
 __global__ __launch_bounds__(64) void k_encode_cur(Dev d, void *planes)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     Board b = d.cur[g];
     const int p = d.ply[g];
-    encode_position(d, g, b, 0, p, p, lane, s, planes);
+    encode_position(d, g, b, 0, p, p, lane, s, planes, r);
 }
 
 __global__ __launch_bounds__(64) void k_greedy(Dev d, const float *pol, const uint8_t *mask,
                                                int push, u16 *moves_out)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (lane == 0) moves_out[g] = NO_MOVE;
-    if (mask && !mask[g]) return;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    if (lane == 0) moves_out[r] = NO_MOVE;
+    if (mask && !mask[r]) return;
     Board b = d.cur[g];
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
     if (mi.n == 0) return;                    // legal[argmax([])] would raise; game is over
-    const int bi = argmax_policy(d, g, s.mv, mi.n, pol, lane);
+    const int bi = argmax_policy(d, r, s.mv, mi.n, pol, lane);
     const u32 mv = s.mv[bi];
     __syncthreads();
-    if (lane == 0) moves_out[g] = (u16)mv;
+    if (lane == 0) moves_out[r] = (u16)mv;
     if (push && d.game_result[g] == RESULT_NONE) game_push(d, g, b, mv, lane, s);
+}
+
+// Game.get_copy (game.py:79-80): deep copy incl. the move stack, slot src -> slot dst
+__global__ __launch_bounds__(64) void k_copy_game(Dev d, int dst, int src)
+{
+    const int lane = threadIdx.x;
+    const int p = d.ply[src];
+    for (int i = lane; i < HIST_RING; i += 64) {
+        d.hist[(size_t)dst * HIST_RING + i] = d.hist[(size_t)src * HIST_RING + i];
+        d.hist_hash[(size_t)dst * HIST_RING + i] = d.hist_hash[(size_t)src * HIST_RING + i];
+    }
+    for (int i = lane; i < p; i += 64)
+        d.rec_moves[(size_t)dst * d.MAXPLY + i] = d.rec_moves[(size_t)src * d.MAXPLY + i];
+    if (lane == 0) {
+        d.cur[dst] = d.cur[src];
+        d.ply[dst] = p;
+        d.game_result[dst] = d.game_result[src];
+        d.root_dead[dst] = 1;
+        d.leaf_kind[dst] = LEAF_NONE;
+    }
 }
 
 // ---- SelfPlayTree seam kernels -------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     if (lane == 0) { d.leaf_kind[g] = LEAF_NONE; d.path_len[g] = 0; }
     if (d.game_result[g] != RESULT_NONE) {
@@ -349,20 +369,20 @@ __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
         d.path_node[nb] = 0;
     }
     __syncthreads();
-    encode_position(d, g, b, 0, p, p, lane, s, planes);
+    encode_position(d, g, b, 0, p, p, lane, s, planes, r);
 }
 
 __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.root_dead[g]) return;
     NodeMeta m = d.meta[(size_t)g * d.N];
-    gather_priors(d, g, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane);
+    gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane);
     if (lane == 0) d.counters[(size_t)g * CNT_N + CNT_EVALS] += 1;
 }
 
 // simulate + backprop (+ priors of the new node's future children) for the pending simulation
-__device__ inline void backup_pending(const Dev &d, int g, int lane, const float *pol2,
+__device__ inline void backup_pending(const Dev &d, int g, int row, int lane, const float *pol2,
                                       const float *val2)
 {
     const int kind = d.leaf_kind[g];
@@ -376,8 +396,8 @@ __device__ inline void backup_pending(const Dev &d, int g, int lane, const float
     if (m.result != RESULT_NONE) {
         v = (double)m.result;                          // state.get_result() (mctree.py:268)
     } else {
-        v = (double)val2[g];                           // python float of the f32 value head
-        gather_priors(d, g, eb, m.edge0, m.nmoves, pol2, lane);
+        v = (double)val2[row];                           // python float of the f32 value head
+        gather_priors(d, row, eb, m.edge0, m.nmoves, pol2, lane);
         evals = 1;                                     // policy/value(S2)
     }
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
@@ -402,18 +422,18 @@ __device__ inline void backup_pending(const Dev &d, int g, int lane, const float
 
 __global__ __launch_bounds__(64) void k_backup(Dev d, const float *pol2, const float *val2)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.root_dead[g]) return;
-    backup_pending(d, g, lane, pol2, val2);
+    backup_pending(d, g, r, lane, pol2, val2);
 }
 
 __global__ __launch_bounds__(64) void k_select_expand(Dev d, const float *pol2, const float *val2,
                                                       void *planes1)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.root_dead[g]) return;
-    backup_pending(d, g, lane, pol2, val2);
+    backup_pending(d, g, r, lane, pol2, val2);
 
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     const bool legacy = (d.flags & 1u) != 0;
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(64) void k_select_expand(Dev d, const float *pol2, 
                     d.leaf_kind[g] = LEAF_NEW_REPLY;
                 }
                 __syncthreads();
-                encode_position(d, g, e.b, 2 * level - 1, p, p, lane, s, planes1);
+                encode_position(d, g, e.b, 2 * level - 1, p, p, lane, s, planes1, r);
             }
             break;
         }
@@ -518,14 +538,14 @@ __global__ __launch_bounds__(64) void k_select_expand(Dev d, const float *pol2, 
 __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *planes2)
 {
     __shared__ WaveLds s;
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.root_dead[g] || d.leaf_kind[g] != LEAF_NEW_REPLY) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     const int c = d.leaf_node[g], level = d.path_len[g], n1 = d.s1_n[g], p = d.ply[g];
     Board s1 = d.nb1[nb + c];
     // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
     const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
-    const int bi = argmax_policy(d, g, mv1, n1, pol1, lane);
+    const int bi = argmax_policy(d, r, mv1, n1, pol1, lane);
     const u32 reply = mv1[bi];
     Board s2 = apply_move(s1, reply);
     PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);
@@ -544,24 +564,24 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
         d.leaf_kind[g] = LEAF_NEW_S2;
     }
     __syncthreads();
-    encode_position(d, g, e.b, 2 * level, p, p, lane, s, planes2);
+    encode_position(d, g, e.b, 2 * level, p, p, lane, s, planes2, r);
 }
 
 __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, int32_t *visits,
                                                       double *values, float *priors, u16 *moves,
                                                       u16 *replies, int32_t *root_visits)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     if (d.root_dead[g]) {
-        if (lane == 0) { nchild[g] = 0; root_visits[g] = 0; }
+        if (lane == 0) { nchild[r] = 0; root_visits[r] = 0; }
         return;
     }
     NodeMeta m = d.meta[nb];
-    if (lane == 0) { nchild[g] = m.nexp; root_visits[g] = d.root_visits[g]; }
+    if (lane == 0) { nchild[r] = m.nexp; root_visits[r] = d.root_visits[g]; }
     for (int k = lane; k < m.nexp; k += 64) {
         const size_t e = eb + m.edge0 + (m.nmoves - 1 - k);      // children order = reverse legal
-        const size_t o = (size_t)g * MAX_MOVES + k;
+        const size_t o = (size_t)r * MAX_MOVES + k;
         const int c = d.e_child[e] & CHILD_NONE;
         visits[o] = d.e_visits[e];
         values[o] = d.e_value[e];
@@ -573,10 +593,10 @@ __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, in
 
 __global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u16 *bm, u16 *am)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (lane != 0) return;
-    bm[g] = NO_MOVE; am[g] = NO_MOVE;
-    const int k = chosen[g];
+    bm[r] = NO_MOVE; am[r] = NO_MOVE;
+    const int k = chosen[r];
     if (k < 0 || d.root_dead[g]) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     NodeMeta m = d.meta[nb];
@@ -591,13 +611,13 @@ __global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u1
     d.hist[hi] = d.nb1[nb + c];
     d.hist_hash[hi] = d.nh1[nb + c];
     d.rec_moves[(size_t)g * d.MAXPLY + p] = d.e_move[e];
-    bm[g] = d.e_move[e];
+    bm[r] = d.e_move[e];
     if (cm.has_s2) {
         hi = (size_t)g * HIST_RING + ((p + 2) & (HIST_RING - 1));
         d.hist[hi] = d.nb2[nb + c];
         d.hist_hash[hi] = d.nh2[nb + c];
         d.rec_moves[(size_t)g * d.MAXPLY + p + 1] = d.n_reply[nb + c];
-        am[g] = d.n_reply[nb + c];
+        am[r] = d.n_reply[nb + c];
     }
     d.cur[g] = d.nb2[nb + c];                 // node state (S1 copy when the game ended there)
     d.ply[g] = np;

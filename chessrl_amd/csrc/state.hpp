@@ -55,6 +55,7 @@ enum Counter { CNT_SIMS = 0, CNT_NODES, CNT_DEPTH, CNT_BRANCH, CNT_EVALS, CNT_TE
 
 struct Dev {
     int G, N, ECAP, MAXPLY;
+    int g0;                            // first slot of the active window (I/O rows are window-relative)
     u32 flags;
     // games
     Board *cur;

@@ -1,0 +1,165 @@
+"""Lockstep search engine: G independent self-play games advance one MCTS
+simulation per step on one MI355X.
+
+This is the host-side driver of the HIP kernels behind the reference's
+``SelfPlayTree.search_move`` (/root/reference/src/chessrl/mctree.py:159-214).
+One *step* = one ``explore_tree`` for every game:
+
+    crl_sim_select_expand   backprop(previous sim) + select + expand up to S1
+    evaluator(planes S1)    tower forward #1  -> policy(S1)      (opponent reply)
+    crl_sim_reply           greedy reply, S2, Node(S2), encode S2
+    evaluator(planes S2)    tower forward #2  -> policy(S2), value(S2)
+
+All four are enqueued on one HIP stream with no host synchronisation and are
+captured once into a hipGraph (torch.cuda.CUDAGraph) that is replayed S times
+per move.  Tensors never leave HBM: the encoder kernels write the tower's fp16
+NHWC input in place and the search kernels read the tower's fp32 outputs in
+place (``torch.Tensor.data_ptr()`` across the C-ABI).
+
+Sequential ``threads=1`` semantics of the reference (the only deterministic
+mode): per game, simulations are strictly ordered.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def compute_policy(visits, root_visits, nb_moves, noise=True, rng=None):
+    """SelfPlayTree.compute_policy (mctree.py:305-322) on host numpy.
+
+    ``visits`` in children order.  ``rng``: a numpy Generator/RandomState or
+    None for the global ``np.random`` stream the reference draws from.
+    """
+    tau = 1
+    if nb_moves >= 30:
+        tau = nb_moves / (1 + np.power(nb_moves, 1.3))
+    policy = np.array([np.power(v, 1 / tau) for v in visits]) / np.power(root_visits, 1 / tau)
+    if noise:
+        epsilon = 0.25
+        policy = (1 - epsilon) * policy + (rng or np.random).dirichlet([0.03] * len(visits))
+    return policy
+
+
+class LockstepEngine(object):
+    """G games x one search tree each on one GPU.
+
+    evaluator(planes[G,8,8,128] fp16 cuda) -> (policy[G,1968] f32, value[G] f32) cuda tensors.
+    """
+
+    def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
+                 numpy_promotion="nep50", use_graph=True):
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
+        if numpy_promotion not in ("nep50", "legacy"):
+            raise ValueError("numpy_promotion must be 'nep50' or 'legacy'")
+        self.G, self.max_sims = n_games, max_sims
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.ctx = _lib.Context(n_games, max_sims, max_plies=max_plies, device=device,
+                                numpy_legacy=(numpy_promotion == "legacy"))
+        self.evaluator = evaluator
+        G = n_games
+        self.planes_s1 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
+        self.planes_s2 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
+        self.pol_s1 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
+        self.pol_s2 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
+        self.val_s2 = torch.zeros((G,), dtype=torch.float32, device=self.dev)
+        self.use_graph = use_graph
+        self._graph = None
+        self._bind_stream()
+
+    # ---- plumbing ---------------------------------------------------------------------
+    def _bind_stream(self):
+        self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def close(self):
+        self._graph = None
+        self.ctx.close()
+
+    def _eval_into(self, planes, pol_out, val_out):
+        pol, val = self.evaluator(planes)
+        pol_out.copy_(pol)
+        if val_out is not None:
+            val_out.copy_(val)
+
+    def _step_body(self):
+        c = self.ctx
+        c.sim_select_expand(self.pol_s2.data_ptr(), self.val_s2.data_ptr(), self.planes_s1.data_ptr())
+        self._eval_into(self.planes_s1, self.pol_s1, None)
+        c.sim_reply(self.pol_s1.data_ptr(), self.planes_s2.data_ptr())
+        self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
+
+    def _capture(self):
+        # warm the evaluator (library handles, autotuning) outside of capture
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.evaluator(self.planes_s1)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._bind_stream()              # kernels must land on the capturing stream
+            self._step_body()
+        self._bind_stream()
+        self._graph = g
+
+    def step(self):
+        """One simulation for every game (enqueue only, no host sync)."""
+        if self.use_graph:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._step_body()
+
+    # ---- SelfPlayTree surface -------------------------------------------------------------
+    def search_begin(self):
+        """Tree.__init__ for every slot + the root's policy (priors of its children)."""
+        self._bind_stream()
+        self.ctx.search_begin(self.planes_s2.data_ptr())
+        self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
+        self.ctx.search_root_priors(self.pol_s2.data_ptr())
+
+    def search(self, n_sims):
+        """search_begin + n_sims lockstep simulations + the last backprop."""
+        if n_sims > self.max_sims:
+            raise ValueError("n_sims exceeds the max_sims this engine was created with")
+        self.search_begin()
+        for _ in range(n_sims):
+            self.step()
+        self.ctx.sim_backup(self.pol_s2.data_ptr(), self.val_s2.data_ptr())
+
+    def root_children(self):
+        return self.ctx.root_children()
+
+    def advance(self, chosen):
+        return self.ctx.advance(chosen)
+
+    # ---- Game surface (batched) --------------------------------------------------------------
+    def reset(self, mask=None):
+        self._bind_stream()
+        self.ctx.reset_games(mask)
+
+    def greedy_move(self, mask=None, push=True):
+        """agent.best_move(game, real_game=True) for the masked slots (+ gam.move(...))."""
+        self._bind_stream()
+        self.ctx.encode(self.planes_s1.data_ptr())
+        self._eval_into(self.planes_s1, self.pol_s1, None)
+        return self.ctx.greedy_moves(self.pol_s1.data_ptr(), mask=mask, push=push)
+
+    def load_moves(self, move_lists):
+        """Replay per-slot move id sequences from the start position (tests / Game copies)."""
+        self.reset()
+        n = max((len(m) for m in move_lists), default=0)
+        for i in range(n):
+            mv = np.full(self.G, _lib.NO_MOVE, dtype=np.uint16)
+            for g, ml in enumerate(move_lists):
+                if i < len(ml):
+                    mv[g] = ml[i]
+            ok = self.ctx.push_moves(mv)
+            for g, ml in enumerate(move_lists):
+                if i < len(ml) and not ok[g]:
+                    raise ValueError("illegal move %d in sequence of slot %d" % (i, g))

@@ -1,0 +1,197 @@
+"""Residual policy/value tower on MFMA (PyTorch-ROCm, fp16, channels-last).
+
+Host-side mirror of the reference's ``ChessModel``
+(/root/reference/src/chessrl/model.py:15-81): same topology and Keras inference
+semantics, parametrised by (blocks, filters) for the
+BASELINE configs; the reference's own values are (10, 256).  Forward only --
+training (model.py:69-72,83-99) is out of scope of this path.
+
+MI355X design notes: the input is the encoder kernel's fp16 NHWC [B,8,8,128]
+buffer used in place (channel 127 is a zero pad, so K = 9*128 is a multiple of
+the MFMA K-step); BatchNorm is folded into the preceding conv in fp32 before
+the cast to fp16; softmax / tanh run in fp32.  Weights are exchanged as a flat
+``name -> ndarray`` dict in Keras layouts (conv HWIO, dense (in,out)), saved as
+``.npz`` (the reference's ``.h5`` needs h5py, absent here).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_EPS = 1e-3            # keras.layers.BatchNormalization default
+N_POLICY = 1968
+IN_PLANES = 127
+PAD_PLANES = 128
+
+
+def init_weights(blocks, filters, seed=0):
+    """Keras-default initialisation: Glorot-uniform kernels, zero biases, BN identity stats."""
+    rng = np.random.default_rng(seed)
+    w = {}
+
+    def glorot(shape, fan_in, fan_out):
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    def conv(name, k, cin, cout):
+        w[name + ".kernel"] = glorot((k, k, cin, cout), k * k * cin, k * k * cout)
+        w[name + ".bias"] = np.zeros(cout, np.float32)
+
+    def bn(name, c):
+        w[name + ".gamma"] = np.ones(c, np.float32)
+        w[name + ".beta"] = np.zeros(c, np.float32)
+        w[name + ".mean"] = np.zeros(c, np.float32)
+        w[name + ".var"] = np.ones(c, np.float32)
+
+    def dense(name, cin, cout):
+        w[name + ".kernel"] = glorot((cin, cout), cin, cout)
+        w[name + ".bias"] = np.zeros(cout, np.float32)
+
+    conv("stem", 3, IN_PLANES, filters)
+    for i in range(blocks):
+        conv("block%d.conv1" % i, 3, filters, filters)
+        bn("block%d.bn1" % i, filters)
+        conv("block%d.conv2" % i, 3, filters, filters)
+        bn("block%d.bn2" % i, filters)
+    conv("policy.conv", 1, filters, 2)
+    bn("policy.bn", 2)
+    dense("policy.dense", 128, N_POLICY)
+    conv("value.conv", 1, filters, 1)
+    bn("value.bn", 1)
+    dense("value.dense1", 64, 256)
+    dense("value.dense2", 256, 1)
+    w["meta.blocks"] = np.array(blocks)
+    w["meta.filters"] = np.array(filters)
+    return w
+
+
+def _fold(w, conv, bn=None):
+    """(OIHW fp32 kernel, bias) of `conv` with the following BatchNorm folded in."""
+    k = torch.from_numpy(np.asarray(w[conv + ".kernel"], np.float32)).permute(3, 2, 0, 1).contiguous()
+    b = torch.from_numpy(np.asarray(w[conv + ".bias"], np.float32)).clone()
+    if bn is not None:
+        g = torch.from_numpy(np.asarray(w[bn + ".gamma"], np.float32))
+        beta = torch.from_numpy(np.asarray(w[bn + ".beta"], np.float32))
+        mean = torch.from_numpy(np.asarray(w[bn + ".mean"], np.float32))
+        var = torch.from_numpy(np.asarray(w[bn + ".var"], np.float32))
+        s = g / torch.sqrt(var + BN_EPS)
+        k = k * s.view(-1, 1, 1, 1)
+        b = (b - mean) * s + beta
+    return k, b
+
+
+class Tower(nn.Module):
+    """Inference tower; input (B,128,8,8) channels_last fp16, i.e. NHWC memory."""
+
+    def __init__(self, blocks, filters):
+        super().__init__()
+        self.blocks_n, self.filters = blocks, filters
+        self.stem = nn.Conv2d(PAD_PLANES, filters, 3, padding=1)
+        self.conv1 = nn.ModuleList([nn.Conv2d(filters, filters, 3, padding=1) for _ in range(blocks)])
+        self.conv2 = nn.ModuleList([nn.Conv2d(filters, filters, 3, padding=1) for _ in range(blocks)])
+        self.policy_conv = nn.Conv2d(filters, 2, 1)
+        self.policy_fc = nn.Linear(128, N_POLICY)
+        self.value_conv = nn.Conv2d(filters, 1, 1)
+        self.value_fc1 = nn.Linear(64, 256)
+        self.value_fc2 = nn.Linear(256, 1)
+
+    @torch.no_grad()
+    def load_keras_dict(self, w):
+        k, b = _fold(w, "stem")
+        kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
+        kp[:, :IN_PLANES] = k
+        self.stem.weight.copy_(kp)
+        self.stem.bias.copy_(b)
+        for i in range(self.blocks_n):
+            for conv, name, bn in ((self.conv1[i], "block%d.conv1" % i, "block%d.bn1" % i),
+                                   (self.conv2[i], "block%d.conv2" % i, "block%d.bn2" % i)):
+                k, b = _fold(w, name, bn)
+                conv.weight.copy_(k)
+                conv.bias.copy_(b)
+        for conv, name, bn in ((self.policy_conv, "policy.conv", "policy.bn"),
+                               (self.value_conv, "value.conv", "value.bn")):
+            k, b = _fold(w, name, bn)
+            conv.weight.copy_(k)
+            conv.bias.copy_(b)
+        for fc, name in ((self.policy_fc, "policy.dense"), (self.value_fc1, "value.dense1"),
+                         (self.value_fc2, "value.dense2")):
+            fc.weight.copy_(torch.from_numpy(np.asarray(w[name + ".kernel"], np.float32)).t())
+            fc.bias.copy_(torch.from_numpy(np.asarray(w[name + ".bias"], np.float32)))
+
+    def forward(self, x):
+        x = self.stem(x)                                     # no BN / activation (model.py:33-34)
+        for c1, c2 in zip(self.conv1, self.conv2):
+            y = F.relu(c1(x))
+            y = c2(y)
+            x = F.relu(x + y)
+        b = x.shape[0]
+        x = x.float()                                        # heads are tiny: run them in fp32
+        p = F.relu(self.policy_conv(x)).permute(0, 2, 3, 1).reshape(b, 128)   # Keras Flatten (h,w,c)
+        p = torch.softmax(self.policy_fc(p), dim=-1)
+        v = F.relu(self.value_conv(x)).permute(0, 2, 3, 1).reshape(b, 64)
+        v = F.relu(self.value_fc1(v))
+        v = torch.tanh(self.value_fc2(v))
+        return p, v[:, 0]
+
+    def cast_for_inference(self, device, dtype):
+        """Trunk (stem + residual blocks) in `dtype` on MFMA, heads in fp32."""
+        self.to(device)
+        for m in [self.stem] + list(self.conv1) + list(self.conv2):
+            m.to(dtype)
+        return self.to(memory_format=torch.channels_last).eval()
+
+
+class ChessModel(object):
+    """Mirror of the reference ``ChessModel`` (model.py:15-81), forward only.
+
+    ``predict(inp)`` takes (B,8,8,127) like Keras ``model.predict`` and returns
+    ``[policy (B,1968), value (B,1)]`` numpy arrays.  ``__call__(planes)`` is the
+    device-resident path the engine uses: fp16 NHWC [B,8,8,128] CUDA tensor in,
+    (policy f32 [B,1968], value f32 [B]) CUDA tensors out.
+    """
+
+    def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
+                 dtype=torch.float16, seed=0):
+        if compile_model:
+            raise NotImplementedError("training is out of scope of the self-play simulation path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
+        self.dtype = dtype
+        if isinstance(weights, str):
+            weights = dict(np.load(weights))
+        if weights is None:
+            weights = init_weights(blocks, filters, seed)
+        self.load_dict(weights)
+
+    def load_dict(self, weights):
+        self.weights = weights
+        blocks, filters = int(weights["meta.blocks"]), int(weights["meta.filters"])
+        net = Tower(blocks, filters)
+        net.load_keras_dict(weights)
+        self.net = net.cast_for_inference(self.device, self.dtype)
+        self.blocks, self.filters = blocks, filters
+
+    def load_weights(self, weights_path):
+        self.load_dict(dict(np.load(weights_path)))
+
+    def save_weights(self, weights_path):
+        np.savez(weights_path, **self.weights)
+
+    @torch.no_grad()
+    def __call__(self, planes):
+        x = planes.to(self.dtype).permute(0, 3, 1, 2)         # NHWC memory viewed as NCHW
+        return self.net(x)
+
+    @torch.no_grad()
+    def predict(self, inp):
+        a = torch.as_tensor(np.asarray(inp))
+        x = torch.zeros((a.shape[0], 8, 8, PAD_PLANES), dtype=self.dtype, device=self.device)
+        x[..., :IN_PLANES] = a.to(self.device, self.dtype)
+        p, v = self(x)
+        return [p.cpu().numpy(), v.cpu().numpy()[:, None]]
+
+    def macs_per_eval(self):
+        """MACs of one forward."""
+        f, b = self.filters, self.blocks
+        return 73152 * f + 1152 * f * f * b + 192 * f + 268544

@@ -1,0 +1,209 @@
+"""Self-play driver -- host mirror of the reference's ``selfplay.py``.
+
+``play_game(agent)`` is the reference's per-game loop
+(/root/reference/src/chessrl/selfplay.py:59-84) on the drop-in ``Game`` / ``Agent``
+objects.  ``SelfPlayRunner`` is the MI355X-first form of the same loop: thousands of
+independent games in lockstep on one GPU (one rank), finished slots refilled at move
+boundaries so the batch stays full, records gathered across ranks at the end
+(``records.gather_records``).  Games shard by ``game_id % world``; every per-game random
+stream (colour, Dirichlet noise) is keyed by the GLOBAL game id, so what a game plays
+does not depend on the number of GPUs.
+
+The training half of the reference's ``main`` (selfplay.py:98-108,157-163) is out of
+scope; the CLI keeps ``modeldir --games --threads --debug`` and adds the knobs the
+reference hard-codes (``--sims`` 900 in selfplay.py:76, net size, parallel games).
+"""
+import argparse
+import logging
+import os
+import random
+import time
+
+import numpy as np
+
+from . import _lib
+from .engine import LockstepEngine, compute_policy
+from .records import GameRecord
+
+log = logging.getLogger("chessrl_amd.selfplay")
+
+
+def get_model_path(directory):
+    """Newest ``model-<v>.npz`` of a directory (selfplay.py:33-56, with .npz for .h5)."""
+    path = directory + "/model-0.npz"
+    models = [f for f in os.listdir(directory) if f.endswith("npz")]
+    if len(models) > 0:
+        max_v = max([m.split("-")[1] for m in models])
+        m = [model for model in models if model.endswith(max_v)][0]
+        path = directory + "/" + m
+    return path
+
+
+def play_game(agent, max_iters=900):
+    """One game, reference-shaped (selfplay.py:59-84): returns the finished ``Game``."""
+    from .game import Game
+    player_color = True if random.random() >= 0.5 else False
+    gam = Game(player_color=player_color)
+    agent.color = player_color
+    if player_color is False:
+        gam.move(agent.best_move(gam, real_game=True))
+    while gam.get_result() is None:
+        start = time.perf_counter()
+        bm, am = agent.best_move(gam, real_game=False, ai_move=True, max_iters=max_iters)
+        gam.move(bm)
+        gam.move(am)
+        log.debug("\tMade move: %s, took: %.2f secs", bm, time.perf_counter() - start)
+    log.debug(gam.get_history())
+    return gam
+
+
+def game_color(seed, game_id):
+    """Per-game colour stream: ``random.random() >= .5`` (selfplay.py:62) keyed by game id."""
+    return random.Random((seed << 20) ^ game_id).random() >= 0.5
+
+
+class SelfPlayRunner(object):
+    """Lockstep self-play of ``n_parallel`` games on one GPU (one rank of ``world``)."""
+
+    def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
+                 max_plies=2048, numpy_promotion="nep50", use_graph=True, total_games=None):
+        self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
+                                     numpy_promotion=numpy_promotion, use_graph=use_graph)
+        self.G, self.sims, self.seed, self.noise = n_parallel, sims, seed, noise
+        self.rank, self.world = rank, world
+        self.total_games = total_games           # global cap on started games (None = endless)
+        self.max_plies = max_plies
+        self.next_local = 0                      # k-th game of this rank has id rank + world*k
+        self.game_id = np.full(n_parallel, -1, dtype=np.int64)
+        self.color = np.zeros(n_parallel, dtype=bool)
+        self.rngs = [None] * n_parallel
+        self.finished = []
+        self.moves_played = 0
+        self.sims_run = 0
+        self._start(np.ones(n_parallel, dtype=bool))
+
+    # ---- slot management ------------------------------------------------------------------
+    def _start(self, mask):
+        """(Re)start the masked slots with fresh games; black-player games get the opponent's
+        greedy opening move first (selfplay.py:68-70)."""
+        opening = np.zeros(self.G, dtype=np.uint8)
+        reset = np.zeros(self.G, dtype=np.uint8)
+        for g in np.nonzero(mask)[0]:
+            gid = self.rank + self.world * self.next_local
+            if self.total_games is not None and gid >= self.total_games:
+                self.game_id[g] = -1
+                continue
+            self.next_local += 1
+            self.game_id[g] = gid
+            self.color[g] = game_color(self.seed, gid)
+            self.rngs[g] = np.random.default_rng([self.seed, gid])
+            reset[g] = 1
+            opening[g] = 0 if self.color[g] else 1
+        if reset.any():
+            self.engine.reset(reset)
+        if opening.any():
+            self.engine.greedy_move(mask=opening, push=True)
+
+    def active(self):
+        return self.game_id >= 0
+
+    # ---- one move for every game --------------------------------------------------------------
+    def play_move(self):
+        """search_move + the two pushes for every running game; harvest and refill finished
+        slots.  Returns the number of simulations run."""
+        eng = self.engine
+        eng.search(self.sims)
+        rc = eng.root_children()
+        _, plies, _ = eng.ctx.records(with_moves=False)
+        chosen = np.full(self.G, -1, dtype=np.int32)
+        live = 0
+        for g in range(self.G):
+            n = int(rc["nchild"][g])
+            if n == 0 or self.game_id[g] < 0:
+                continue
+            pol = compute_policy(rc["visits"][g, :n], rc["root_visits"][g], int(plies[g]),
+                                 noise=self.noise, rng=self.rngs[g])
+            chosen[g] = int(np.argmax(pol))
+            live += 1
+        eng.advance(chosen)
+        self.moves_played += live
+        self.sims_run += live * self.sims
+        res = eng.ctx.results()
+        done = (res != _lib.RESULT_NONE) & self.active()
+        if done.any():
+            moves, plies, res = eng.ctx.records()
+            for g in np.nonzero(done)[0]:
+                self.finished.append(GameRecord(self.game_id[g], moves[g, :plies[g]], int(res[g]),
+                                                bool(self.color[g])))
+            self._start(done)
+        return live * self.sims
+
+    def run(self, n_games=None, max_moves=None):
+        """Play until ``n_games`` records exist on this rank (or ``max_moves`` move rounds)."""
+        rounds = 0
+        while self.active().any():
+            if n_games is not None and len(self.finished) >= n_games:
+                break
+            if max_moves is not None and rounds >= max_moves:
+                break
+            self.play_move()
+            rounds += 1
+        return self.finished
+
+    def close(self):
+        self.engine.close()
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Plays self-play chess games on MI355X GPUs and "
+                                     "stores the game records.")
+    parser.add_argument("model_dir", metavar="modeldir",
+                        help="where to load the model from and store the records")
+    parser.add_argument("--games", type=int, default=1)
+    parser.add_argument("--threads", type=int, default=6,
+                        help="accepted for compatibility (simulations are sequential per game)")
+    parser.add_argument("--debug", action="store_true", default=False)
+    parser.add_argument("--sims", type=int, default=900, help="MCTS iterations per move")
+    parser.add_argument("--parallel", type=int, default=None, help="games in lockstep per GPU")
+    parser.add_argument("--blocks", type=int, default=10)
+    parser.add_argument("--filters", type=int, default=256)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--no-noise", action="store_true")
+    args = parser.parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO)
+
+    import torch
+    import torch.distributed as dist
+    from .model import ChessModel
+    from .records import dumps, gather_records
+    rank, world, local = 0, 1, 0
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    os.makedirs(args.model_dir, exist_ok=True)
+    path = get_model_path(args.model_dir)
+    weights = path if os.path.exists(path) else None
+    model = ChessModel(weights=weights, blocks=args.blocks, filters=args.filters,
+                       device="cuda:%d" % local, seed=args.seed)
+    per_rank = (args.games + world - 1) // world
+    parallel = args.parallel or min(per_rank, 4096)
+    runner = SelfPlayRunner(model, parallel, args.sims, seed=args.seed, noise=not args.no_noise,
+                            rank=rank, world=world, device=local, total_games=args.games)
+    t0 = time.perf_counter()
+    recs = runner.run()
+    dt = time.perf_counter() - t0
+    log.info("rank %d: %d games, %d sims in %.1fs (%.0f sims/s)", rank, len(recs), runner.sims_run,
+             dt, runner.sims_run / max(dt, 1e-9))
+    allrecs = gather_records(recs, runner.max_plies)
+    if rank == 0:
+        with open(os.path.join(args.model_dir, "gameplays.json"), "w") as f:
+            f.write(dumps(allrecs))
+        log.info("wrote %d game records", len(allrecs))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

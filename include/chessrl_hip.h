@@ -70,6 +70,9 @@ void crl_destroy(crl_ctx *ctx);
 int  crl_set_stream(crl_ctx *ctx, void *hip_stream);
 int  crl_sync(crl_ctx *ctx);                 /* wait for the stream; report device errors */
 const char *crl_last_error(crl_ctx *ctx);    /* ctx may be NULL for crl_create failures   */
+/* Restrict every later call to slots [first, first+count): host arrays and dev_ rows are then
+ * indexed relative to `first` and sized by `count` instead of G (default window = all G). */
+int  crl_set_window(crl_ctx *ctx, int first, int count);
 int  crl_max_games(crl_ctx *ctx);
 int  crl_max_sims(crl_ctx *ctx);
 
@@ -84,6 +87,9 @@ int  crl_reset_games(crl_ctx *ctx, const uint8_t *mask);
  * EMPTY move stack (tests: arbitrary positions). */
 int  crl_set_positions(crl_ctx *ctx, const crl_board *boards, int n);
 int  crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n);
+/* Game.get_copy (game.py:79-80): slot dst becomes a deep copy (board AND move stack) of
+ * slot src; absolute slot numbers, independent of the window. */
+int  crl_copy_game(crl_ctx *ctx, int dst, int src);
 /* Game.get_legal_moves (game.py:43-57): python-chess generation order. */
 int  crl_legal_moves(crl_ctx *ctx, uint16_t *moves /*G x 256*/, int32_t *counts /*G*/);
 /* Game.move (game.py:28-41): applied iff in the legal list; ok[g] = 1/0; CRL_NO_MOVE skips. */

@@ -72,13 +72,14 @@ class OracleAgent(object):
         return policy
 
     def best_move(self, game, real_game=False, max_iters=900, ai_move=True, verbose=False,
-                  noise=True, mode="nep50"):
+                  noise=True, mode="nep50", rng=None):
         best = NULL_MOVE
         if real_game:
             policy = self.predict_policy(game)
             best = game.get_legal_moves()[int(np.argmax(policy))]
         elif game.get_result() is None:
-            best = search(game, self, max_iters, noise=noise, ai_move=ai_move, mode=mode).moves
+            best = search(game, self, max_iters, noise=noise, ai_move=ai_move, mode=mode,
+                          rng=rng).moves
         return best
 
     def get_copy(self):
@@ -203,7 +204,7 @@ def compute_policy(visits, root_visits, nb_moves, noise=True, rng=None):
 
 
 def play_game(agent, max_iters=900, noise=True, mode="nep50", player_color=None,
-              pyrandom=None, max_moves=None):
+              pyrandom=None, max_moves=None, rng=None):
     """selfplay.play_game (selfplay.py:59-84) on OracleGame; returns the Game."""
     import random
     if player_color is None:
@@ -215,7 +216,7 @@ def play_game(agent, max_iters=900, noise=True, mode="nep50", player_color=None,
     n = 0
     while gam.get_result() is None:
         bm, am = agent.best_move(gam, real_game=False, ai_move=True, max_iters=max_iters,
-                                 noise=noise, mode=mode)
+                                 noise=noise, mode=mode, rng=rng)
         gam.move(bm)
         gam.move(am)
         n += 1

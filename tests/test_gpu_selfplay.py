@@ -1,0 +1,99 @@
+"""GPU parity: whole self-play games (lockstep runner, refill of finished slots, records,
+drop-in Game/Agent/SelfPlayTree objects) vs the reference-shaped CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import mcts_oracle
+from oracle.chess_oracle import OracleGame, move_to_uci
+from oracle.fakenet import FakeNet
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_game(net, gid, seed, sims, noise, max_moves=None):
+    from chessrl_amd.selfplay import game_color
+    agent = mcts_oracle.OracleAgent(net)
+    return mcts_oracle.play_game(agent, max_iters=sims, noise=noise, player_color=game_color(seed, gid),
+                                 rng=np.random.default_rng([seed, gid]), max_moves=max_moves)
+
+
+def test_full_games_with_refill_match_oracle():
+    """5 complete games through 3 lockstep slots (so slots are refilled), Dirichlet noise ON
+    with per-game streams; every record must equal the oracle's game move for move."""
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=21, prior_shift=30)
+    seed, sims = 5, 6
+    run = SelfPlayRunner(net.to("cuda:0"), n_parallel=3, sims=sims, seed=seed, noise=True,
+                         total_games=5, max_plies=2048)
+    recs = sorted(run.run(), key=lambda r: r.game_id)
+    assert [r.game_id for r in recs] == [0, 1, 2, 3, 4]
+    for r in recs:
+        g = oracle_game(net, r.game_id, seed, sims, True)
+        h = g.get_history()
+        assert r.get_history()["moves"] == h["moves"], r.game_id
+        assert r.result == h["result"] and r.result is not None
+        assert r.player_color == g.player_color
+    cnt = run.engine.ctx.counters()
+    assert cnt["sims"] == run.sims_run
+    run.close()
+
+
+def test_two_rank_sharding_plays_the_same_games():
+    """game id -> rank id % world: two 'ranks' run one after the other on this GPU must
+    produce exactly the games a single rank produces (streams keyed by global game id)."""
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=8, prior_shift=29).to("cuda:0")
+    kw = dict(sims=5, seed=2, noise=True, max_plies=2048)
+    one = SelfPlayRunner(net, n_parallel=4, total_games=4, **kw)
+    base = {r.game_id: r for r in one.run()}
+    one.close()
+    got = {}
+    for rank in range(2):
+        r = SelfPlayRunner(net, n_parallel=2, total_games=4, rank=rank, world=2, **kw)
+        got.update({x.game_id: x for x in r.run()})
+        r.close()
+    assert sorted(got) == sorted(base) == [0, 1, 2, 3]
+    for k in base:
+        assert got[k] == base[k]
+
+
+def test_dropin_objects_match_oracle():
+    """Game / Agent / SelfPlayTree objects (the reference's API surface) on the HIP path."""
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.game import Game
+    from chessrl_amd import mctree, netencoder
+    from oracle import encoder_oracle
+    net = FakeNet(seed=4, prior_shift=29)
+    agent = Agent(True, model=net.to("cuda:0"))
+    oagent = mcts_oracle.OracleAgent(net)
+    g, og = Game(), OracleGame()
+    assert agent.move_encodings == oagent.move_encodings
+    for u in ["e2e4", "c7c5", "g1f3", "d7d6", "f1b5"]:
+        assert g.move(u) and og.move(u)
+    assert not g.move("e1g1x") and not g.move("00000") and not g.move("a1a8")
+    assert g.get_legal_moves() == og.get_legal_moves() and len(g) == len(og) == 5
+    assert g.turn == og.turn and g.get_result() is None and g.get_fen() == og.get_fen()
+    assert np.array_equal(netencoder.get_game_state(g), encoder_oracle.get_game_state(og))
+    assert np.array_equal(netencoder.get_game_state(g, flipped=True),
+                          encoder_oracle.get_game_state(og, flipped=True))
+    c = g.get_copy()
+    assert c.move("b8c6") and len(c) == 6 and len(g) == 5          # deep copy incl. move stack
+    assert c.get_history()["moves"][:5] == g.get_history()["moves"]
+    # predict_* / best_move(real_game=True)
+    assert np.array_equal(np.array(agent.predict_policy(g), dtype=np.float32),
+                          np.array(oagent.predict_policy(og), dtype=np.float32))
+    assert agent.predict_outcome(g) == oagent.predict_outcome(og)
+    assert agent.best_move(g, real_game=True) == oagent.best_move(og, real_game=True)
+    # SelfPlayTree.search_move
+    tree = mctree.SelfPlayTree(g, threads=6)
+    mv = tree.search_move(agent, max_iters=40, noise=False, ai_move=True)
+    r = mcts_oracle.search(og, oagent, 40, noise=False)
+    assert mv == r.moves
+    assert [c.visits for c in tree.root.children] == r.visits and tree.root.visits == r.root_visits
+    # agent.best_move(real_game=False) draws its noise from the global np.random stream
+    np.random.seed(7)
+    bm = agent.best_move(g, real_game=False, max_iters=40)
+    np.random.seed(7)
+    assert bm == oagent.best_move(og, real_game=False, max_iters=40, noise=True)
+    g.free()
+    c.free()
