@@ -239,14 +239,17 @@ class Context(object):
         self._ck(self._L.crl_sim_backup(self._h, ctypes.c_void_p(dev_policy_s2),
                                         ctypes.c_void_p(dev_value_s2)), "crl_sim_backup")
 
-    def root_children(self):
+    def root_children(self, fields=None):
+        """Root children statistics in CHILDREN order; ``fields`` limits what is copied back."""
         G = self.G
-        out = {
-            "nchild": np.zeros(G, np.int32), "visits": np.zeros((G, MAX_MOVES), np.int32),
-            "values": np.zeros((G, MAX_MOVES), np.float64), "priors": np.zeros((G, MAX_MOVES), np.float32),
-            "moves": np.zeros((G, MAX_MOVES), np.uint16), "replies": np.zeros((G, MAX_MOVES), np.uint16),
-            "root_visits": np.zeros(G, np.int32),
+        spec = {
+            "nchild": ((G,), np.int32), "visits": ((G, MAX_MOVES), np.int32),
+            "values": ((G, MAX_MOVES), np.float64), "priors": ((G, MAX_MOVES), np.float32),
+            "moves": ((G, MAX_MOVES), np.uint16), "replies": ((G, MAX_MOVES), np.uint16),
+            "root_visits": ((G,), np.int32),
         }
+        out = {k: (np.zeros(sh, dt) if (fields is None or k in fields) else None)
+               for k, (sh, dt) in spec.items()}
         self._ck(self._L.crl_root_children(
             self._h, _ptr(out["nchild"]), _ptr(out["visits"]), _ptr(out["values"]), _ptr(out["priors"]),
             _ptr(out["moves"]), _ptr(out["replies"]), _ptr(out["root_visits"])), "crl_root_children")

@@ -80,6 +80,7 @@ class SelfPlayRunner(object):
         self.finished = []
         self.moves_played = 0
         self.sims_run = 0
+        self._sims_in_move = None
         self._start(np.ones(n_parallel, dtype=bool))
 
     # ---- slot management ------------------------------------------------------------------
@@ -108,12 +109,29 @@ class SelfPlayRunner(object):
         return self.game_id >= 0
 
     # ---- one move for every game --------------------------------------------------------------
-    def play_move(self):
-        """search_move + the two pushes for every running game; harvest and refill finished
-        slots.  Returns the number of simulations run."""
+    def begin_move(self):
+        """Fresh tree per slot (agentdistributed.py:61-63) + the root's priors."""
+        self.engine.search_begin()
+        self._sims_in_move = 0
+
+    def step(self):
+        """One lockstep simulation for every game; runs the move boundary when the budget of
+        ``sims`` per move is reached.  Returns True when a move boundary was crossed."""
+        if self._sims_in_move is None:
+            self.begin_move()
+        self.engine.step()
+        self._sims_in_move += 1
+        if self._sims_in_move >= self.sims:
+            self.end_move()
+            return True
+        return False
+
+    def end_move(self):
+        """Last backprop, compute_policy + argmax on the host, the two pushes, harvest of
+        finished games and refill of their slots."""
         eng = self.engine
-        eng.search(self.sims)
-        rc = eng.root_children()
+        eng.ctx.sim_backup(eng.pol_s2.data_ptr(), eng.val_s2.data_ptr())
+        rc = eng.ctx.root_children(("nchild", "visits", "root_visits"))
         _, plies, _ = eng.ctx.records(with_moves=False)
         chosen = np.full(self.G, -1, dtype=np.int32)
         live = 0
@@ -127,7 +145,8 @@ class SelfPlayRunner(object):
             live += 1
         eng.advance(chosen)
         self.moves_played += live
-        self.sims_run += live * self.sims
+        self.sims_run += live * self._sims_in_move
+        self._sims_in_move = None
         res = eng.ctx.results()
         done = (res != _lib.RESULT_NONE) & self.active()
         if done.any():
@@ -136,7 +155,15 @@ class SelfPlayRunner(object):
                 self.finished.append(GameRecord(self.game_id[g], moves[g, :plies[g]], int(res[g]),
                                                 bool(self.color[g])))
             self._start(done)
-        return live * self.sims
+        return live
+
+    def play_move(self):
+        """search_move + the two pushes for every running game (``sims`` lockstep steps)."""
+        self.begin_move()
+        for _ in range(self.sims):
+            self.engine.step()
+        self._sims_in_move = self.sims
+        return self.end_move() * self.sims
 
     def run(self, n_games=None, max_moves=None):
         """Play until ``n_games`` records exist on this rank (or ``max_moves`` move rounds)."""
