@@ -61,6 +61,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be the copy this process binds, or the tower and
+    # the search kernels would sit on two HIP runtimes (and the second one sees no device)
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         try:
             build()

@@ -43,8 +43,12 @@ class FakeNet(object):
     exercised.  ``quant`` coarsens the outputs to create exact ties.
     """
 
-    def __init__(self, seed=1, prior_shift=29, quant=0, device="cpu"):
-        self.seed, self.prior_shift, self.quant = seed, prior_shift, quant
+    # 10*f32(K) == 10*f32(K+1) when the product is rounded to float32 (numpy >= 2), but not when
+    # it is a float64 product (numpy 1.x): priors K*2^-s and (K+1)*2^-s tie in one mode only.
+    TIE_K = 13421774
+
+    def __init__(self, seed=1, prior_shift=29, quant=0, device="cpu", tie=False):
+        self.seed, self.prior_shift, self.quant, self.tie = seed, prior_shift, quant, tie
         self.device = torch.device(device)
         w = _splitmix(seed, 64 * 127)
         self.w = torch.from_numpy(w.reshape(8, 8, 127)).to(self.device)
@@ -53,7 +57,7 @@ class FakeNet(object):
         self.b = torch.from_numpy(ab[_NPOL + 1:].copy()).to(self.device)
 
     def to(self, device):
-        return FakeNet(self.seed, self.prior_shift, self.quant, device)
+        return FakeNet(self.seed, self.prior_shift, self.quant, device, self.tie)
 
     @torch.no_grad()
     def __call__(self, planes):
@@ -64,6 +68,11 @@ class FakeNet(object):
         u24 = mixed & 0xFFFFFF
         if self.quant:
             u24 = (u24 >> self.quant) << self.quant
+        if self.tie:
+            # two adjacent priors everywhere and one constant value (-0.5): exactly equal Q terms,
+            # so the order of PUCT scores depends on how 10*prior is rounded
+            u24 = torch.cat([self.TIE_K + (u24[:, :_NPOL] & 1),
+                             torch.full_like(u24[:, _NPOL:], 1 << 22)], dim=1)
         pol = u24[:, :_NPOL].to(torch.float32) * (2.0 ** -self.prior_shift)
         val = u24[:, _NPOL].to(torch.float32) * (2.0 ** -23) - 1.0
         return pol, val

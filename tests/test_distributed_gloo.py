@@ -1,0 +1,42 @@
+"""CPU, world_size 2 over gloo: the record gather that follows the sharded self-play."""
+import os
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.game import uci_to_move
+    # rank r owns games r, r+world, ...; rank 1 finished one more game than rank 0
+    mine = [records.GameRecord(rank + world * k, [uci_to_move("e2e4")] * (3 + rank + k), k % 3 - 1,
+                               bool((rank + k) & 1)) for k in range(2 + rank)]
+    allr = records.gather_records(mine, max_plies=64)
+    q.put((rank, [(r.game_id, len(r.moves), r.result, r.player_color) for r in allr]))
+    dist.destroy_process_group()
+
+
+def test_gather_records_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    assert [g[0] for g in got[0]] == [0, 1, 2, 3, 5]            # sorted by global game id
+    assert got[0][1] == (1, 4, -1, True) and got[0][4] == (5, 6, 1, True)
+
+
+def test_gather_records_single_process_is_identity():
+    from chessrl_amd import records
+    recs = [records.GameRecord(5, [1, 2], 0, True), records.GameRecord(1, [3], 1, False)]
+    assert [r.game_id for r in records.gather_records(recs, 8)] == [1, 5]

@@ -156,3 +156,43 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, dtype):
     assert np.abs(kp - epol.numpy()).max() <= 1e-3 and np.abs(kv[:, 0] - eval_.numpy()).max() <= vtol
     assert kp.shape == (32, 1968) and kv.shape == (32, 1)
     eng.close()
+
+
+def test_search_matches_committed_golden_vectors(golden_dir):
+    """HIP search vs tests/golden/mcts_cases.json: the outputs of the reference's own mctree.py
+    (oracle/make_golden.py), both numpy promotion modes, incl. a case where the modes differ."""
+    import json
+    import os
+    import struct
+    from chessrl_amd.engine import LockstepEngine, compute_policy
+    from chessrl_amd.game import move_to_uci as mv_uci
+    cases = json.load(open(os.path.join(golden_dir, "mcts_cases.json")))["cases"]
+    assert any(c["differs_from_other_mode"] for c in cases)
+    for c in cases:
+        net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"], quant=c["quant"], tie=c["tie"])
+        eng = LockstepEngine(net.to("cuda:0"), n_games=1, max_sims=c["sims"], numpy_promotion=c["mode"])
+        eng.load_moves([[uci_to_move(u) for u in c["prefix_moves"]]])
+        eng.search(c["sims"])
+        rc = eng.root_children()
+        n = int(rc["nchild"][0])
+        assert list(rc["visits"][0, :n]) == c["visits"], (c["prefix_seed"], c["mode"])
+        assert rc["root_visits"][0] == c["root_visits"]
+        assert [struct.pack(">d", v).hex() for v in rc["values"][0, :n]] == c["values"]
+        assert [struct.pack(">f", p).hex() for p in rc["priors"][0, :n]] == c["priors"]
+        pol = compute_policy(rc["visits"][0, :n], rc["root_visits"][0], len(c["prefix_moves"]), noise=False)
+        assert [struct.pack(">d", p).hex() for p in pol] == c["policy"]
+        k = int(np.argmax(pol))
+        assert mv_uci(rc["moves"][0, k]) == c["bm"] and mv_uci(rc["replies"][0, k]) == c["am"]
+        eng.close()
+
+
+def test_f64_sqrt_and_divide_are_correctly_rounded():
+    """The PUCT contract leans on IEEE float64 sqrt/divide on the device: check them against
+    numpy through the tower-free path (a torch kernel uses the same hardware ops)."""
+    n = torch.arange(0, 200000, dtype=torch.float64, device="cuda:0")
+    assert np.array_equal(torch.sqrt(n).cpu().numpy(), np.sqrt(n.cpu().numpy()))
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(200000)
+    b = rng.integers(1, 900, 200000).astype(np.float64)
+    got = (torch.from_numpy(a).cuda() / torch.from_numpy(b).cuda()).cpu().numpy()
+    assert np.array_equal(got, a / b)

@@ -1,0 +1,162 @@
+"""CPU: the C-ABI library loads and exports every declared symbol, fails loudly without a GPU;
+host-side logic (labels, compute_policy, records, conversions, tower BN folding)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_oracle, mcts_oracle, tower_oracle
+from oracle.chess_oracle import board_from_fen, board_to_array
+from oracle import chess_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def test_library_exports_every_symbol_declared_in_the_header():
+    from chessrl_amd import _lib
+    text = open(os.path.join(ROOT, "include", "chessrl_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(crl_[a-z_0-9]+)\s*\(", text)))
+    assert declared and sorted(_lib.SYMBOLS) == declared
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure path")
+def test_product_path_fails_loudly_without_gpu():
+    from chessrl_amd import _lib
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    with pytest.raises(_lib.HipLibraryError, match="no HIP device|crl_create failed"):
+        _lib.Context(4, 8)
+    with pytest.raises(_lib.HipLibraryError):
+        LockstepEngine(lambda p: None, 4, 8)
+    with pytest.raises(RuntimeError):
+        ChessModel(blocks=1, filters=8)
+
+
+def test_product_never_imports_the_oracle():
+    """A product path that routes through oracle/ would void every parity claim."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "chessrl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_label_table_matches_reference_golden(golden_dir):
+    from chessrl_amd import _lib
+    from chessrl_amd.game import move_to_uci
+    import hashlib
+    gold = json.load(open(os.path.join(golden_dir, "uci_labels.json")))
+    assert len(gold["labels"]) == 1968 and len(set(gold["labels"])) == 1968
+    assert gold["sha256"] == "e67a413cdbce60252cbcf4714d6e4b88549ecaee5e5a613ee4cdb8d5098d8f7b"
+    assert hashlib.sha256("\n".join(gold["labels"]).encode()).hexdigest() == gold["sha256"]
+    assert [move_to_uci(m) for m in _lib.uci_label_moves()] == gold["labels"]     # C++ generator
+    assert encoder_oracle.get_uci_labels() == gold["labels"]                      # oracle restatement
+    for u, i in (("e2e4", 930), ("g1f3", 1402), ("e1g1", 901), ("e7e8q", 1881), ("h2h1b", 1960)):
+        assert gold["labels"][i] == u
+
+
+def test_uci_and_fen_conversions_agree_with_oracle():
+    from chessrl_amd import game
+    for u in ["e2e4", "a7a8q", "h2g1n", "e1g1", "b7c8r"]:
+        assert game.uci_to_move(u) == chess_oracle.uci_to_move(u)
+        assert game.move_to_uci(game.uci_to_move(u)) == u
+    for bad in ["00000", "e2", "e2e9", "i1a1", "e7e8k", "e7e8x", None, 5]:
+        assert game.uci_to_move(bad) is None
+    fen = "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq e3 12 30"
+    row = game.board_row_from_fen(fen)
+    assert np.array_equal(row, board_to_array(board_from_fen(fen)))
+    assert game.board_fen_from_row(row) == fen.split()[0]
+
+
+def test_compute_policy_matches_oracle_bitwise():
+    from chessrl_amd.engine import compute_policy
+    rng = np.random.default_rng(0)
+    for nb in (0, 12, 29, 30, 31, 77, 200):
+        v = rng.integers(0, 40, size=rng.integers(1, 60)).tolist()
+        rv = sum(v) + 1
+        a = compute_policy(v, rv, nb, noise=False)
+        b = mcts_oracle.compute_policy(v, rv, nb, noise=False)
+        assert np.array_equal(a, b)
+        a = compute_policy(v, rv, nb, noise=True, rng=np.random.default_rng(5))
+        b = mcts_oracle.compute_policy(v, rv, nb, noise=True, rng=np.random.default_rng(5))
+        assert np.array_equal(a, b)
+    np.random.seed(9)
+    a = compute_policy([5, 2, 1], 9, 3, noise=True)
+    np.random.seed(9)
+    b = 0.75 * np.array([5, 2, 1]) / 9 + np.random.dirichlet([0.03] * 3)    # noise NOT scaled by eps
+    assert np.array_equal(a, b)
+
+
+def test_records_roundtrip():
+    from chessrl_amd import records
+    from chessrl_amd.game import uci_to_move
+    recs = [records.GameRecord(7, [uci_to_move(u) for u in ["e2e4", "e7e5", "d1h5"]], None, True, "d"),
+            records.GameRecord(2**33 + 1, [uci_to_move("a7a8q")], -1, False),
+            records.GameRecord(0, [], 0, True)]
+    back = records.unpack(records.pack(recs, 16))
+    assert back == recs and back[1].game_id == 2**33 + 1
+    h = json.loads(records.dumps(recs))
+    assert h[0] == {"moves": ["e2e4", "e7e5", "d1h5"], "result": None, "player_color": True, "date": "d"}
+    again = records.loads(records.dumps(recs))
+    assert [r.get_history()["moves"] for r in again] == [r.get_history()["moves"] for r in recs]
+    with pytest.raises(ValueError):
+        records.pack(recs, 2)
+
+
+def test_game_color_and_model_path(tmp_path):
+    from chessrl_amd import selfplay
+    cols = [selfplay.game_color(3, g) for g in range(64)]
+    assert cols == [selfplay.game_color(3, g) for g in range(64)] and 10 < sum(cols) < 54
+    assert selfplay.get_model_path(str(tmp_path)).endswith("model-0.npz")
+    for v in (1, 3, 2):
+        (tmp_path / ("model-%d.npz" % v)).write_bytes(b"")
+    assert selfplay.get_model_path(str(tmp_path)).endswith("model-3.npz")
+
+
+def test_tower_module_folding_matches_oracle_on_cpu():
+    """BN folding, HWIO->OIHW, the 128-plane pad and Keras Flatten order, in fp32 on the CPU
+    (the fp16 MFMA numerics are checked on the GPU)."""
+    from chessrl_amd import model
+    w = tower_oracle.init_weights(3, 16, seed=2, randomize_bn=True)
+    net = model.Tower(3, 16)
+    net.load_keras_dict(w)
+    net = net.to(memory_format=torch.channels_last).eval()
+    rng = np.random.default_rng(1)
+    planes = (rng.random((5, 8, 8, 127)) < 0.15).astype(np.float32)
+    x = torch.zeros((5, 8, 8, 128))
+    x[..., :127] = torch.from_numpy(planes)
+    with torch.no_grad():
+        p, v = net(x.permute(0, 3, 1, 2))
+    ep, ev = tower_oracle.forward(w, planes)
+    assert (p - ep).abs().max() < 1e-6 and (v - ev).abs().max() < 1e-5
+    assert abs(p.sum(dim=1) - 1).max() < 1e-5 and p.shape == (5, 1968)
+    own = model.init_weights(3, 16, seed=0)
+    assert set(own) == set(w) and all(own[k].shape == w[k].shape for k in w)
+    f, b = 128, 10
+    assert 73152 * f + 1152 * f * f * b + 192 * f + 268544 == 198400256
+
+
+def test_encoder_oracle_known_answers():
+    """Hand-derived: python-chess is absent, so these pin get_game_state."""
+    from oracle.chess_oracle import OracleGame
+    g = OracleGame()
+    s = encoder_oracle.get_game_state(g)
+    assert s.shape == (8, 8, 127)
+    assert s[6, :, 8].all() and s[1, :, 1].all()                # white pawns row 6, black pawns row 1
+    assert s[7, 4, 7 + 6] == 1 and s[0, 4, 6] == 1              # kings: e1 -> row 7 col 4, e8 -> row 0
+    assert s[2:, :, 0].all() and not s[:2, :, 0].any()          # "no black piece here" plane
+    assert s[:, :, 126].all() and not s[:, :, 14:126].any()
+    g.move("e2e4")
+    s2 = encoder_oracle.get_game_state(g)
+    assert np.array_equal(s2[:, :, 14:28], s[:, :, 0:14])       # previous position in history slot 0
+    assert not s2[:, :, 126].any() and s2[4, 4, 8] == 1 and s2[6, 4, 8] == 0
+    assert np.array_equal(encoder_oracle.get_game_state(g, flipped=True), np.rot90(s2, k=2))

@@ -1,0 +1,97 @@
+"""CPU: the C chess oracle against public known answers (perft suite, python-chess README
+listing) and hand-derived rule cases.  The oracle's move ORDER is otherwise unpinned against
+python-chess 0.28.3 (absent from this image) -- see oracle/chess_oracle.c."""
+import pytest
+
+from oracle.chess_oracle import (OracleGame, board_fen, board_from_fen, move_to_uci,
+                                 uci_to_move)
+from tests.util import PERFT_FENS
+
+# https://www.chessprogramming.org/Perft_Results (public known answers)
+PERFT = {
+    "start": ("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", [20, 400, 8902, 197281]),
+    "kiwipete": (PERFT_FENS["kiwipete"], [48, 2039, 97862]),
+    "pos3": (PERFT_FENS["pos3"], [14, 191, 2812, 43238, 674624]),
+    "pos4": (PERFT_FENS["pos4"], [6, 264, 9467, 422333]),
+    "pos4m": (PERFT_FENS["pos4m"], [6, 264, 9467, 422333]),
+    "pos5": (PERFT_FENS["pos5"], [44, 1486, 62379]),
+    "pos6": (PERFT_FENS["pos6"], [46, 2079, 89890]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PERFT))
+def test_perft_known_answers(name):
+    fen, counts = PERFT[name]
+    g = OracleGame(board=board_from_fen(fen))
+    assert [g.perft(d + 1) for d in range(len(counts))] == counts
+
+
+def test_start_position_order_matches_python_chess_listing():
+    # python-chess README: <LegalMoveGenerator ... (Nh3, Nf3, Nc3, Na3, h3, g3, ..., a4)>
+    assert OracleGame().get_legal_moves() == [
+        "g1h3", "g1f3", "b1c3", "b1a3", "h2h3", "g2g3", "f2f3", "e2e3", "d2d3", "c2c3", "b2b3",
+        "a2a3", "h2h4", "g2g4", "f2f4", "e2e4", "d2d4", "c2c4", "b2b4", "a2a4"]
+
+
+def test_generation_order_categories():
+    """pieces (from high->low, to high->low), castling K then Q, pawn captures with promotions
+    Q,R,B,N, single pushes, double pushes, en passant last."""
+    g = OracleGame(board=board_from_fen("r3k2r/1P6/8/3pP3/8/8/P7/R3K2R w KQkq d6 0 2"))
+    mv = g.get_legal_moves()
+    assert mv.index("e1g1") + 1 == mv.index("e1c1")                     # king side first
+    assert mv.index("e1c1") < mv.index("b7a8q")                         # castling before pawns
+    i = mv.index("b7a8q")
+    assert mv[i:i + 4] == ["b7a8q", "b7a8r", "b7a8b", "b7a8n"]          # promotion order
+    assert mv.index("b7a8n") < mv.index("b7b8q") < mv.index("e5e6") < mv.index("a2a3")
+    assert mv.index("a2a3") < mv.index("a2a4") < mv.index("e5d6")       # double pushes, then ep
+    assert mv[-1] == "e5d6"
+    assert mv[0] == "h1h8" and mv[1] == "h1h7"                          # highest from-square first
+
+
+def test_evasions_king_first_then_blocks():
+    g = OracleGame(board=board_from_fen("4k3/8/8/8/7b/8/3N4/R3K3 w Q - 0 1"))
+    mv = g.get_legal_moves()
+    assert mv[:3] == ["e1e2", "e1f1", "e1d1"] and mv[3:] == ["d2f2"] or mv == ["e1e2", "e1f1", "e1d1"]
+    assert "e1c1" not in mv                                             # no castling out of check
+
+
+def test_en_passant_legality():
+    g = OracleGame(board=board_from_fen(PERFT_FENS["ep_pin"]))           # capture would expose the king
+    assert "b5c6" not in g.get_legal_moves()
+    assert (g.board_at(0).state >> 20) & 1 == 0
+    g = OracleGame(board=board_from_fen(PERFT_FENS["ep_check"]))         # ep captures the checking pawn
+    assert "e4d3" in g.get_legal_moves() and (g.board_at(0).state >> 20) & 1 == 1
+
+
+def test_push_semantics():
+    g = OracleGame()
+    assert not g.move("e2e5") and not g.move("00000") and not g.move("e7e5") and len(g) == 0
+    for u in ["e2e4", "e7e5", "g1f3", "b8c6", "f1c4", "g8f6", "e1g1"]:
+        assert g.move(u)
+    b = g.board_at(0)
+    assert board_fen(b) == "r1bqkb1r/pppp1ppp/2n2n2/4p3/2B1P3/5N2/PPPP1PPP/RNBQ1RK1"
+    assert (b.state >> 1) & 15 == 0b1100                                # white rights gone
+    assert (b.state >> 12) & 255 == 5 and b.state & 1 == 0             # clock, black to move
+    assert uci_to_move("e7e8q") == 52 | (60 << 6) | (5 << 12) and move_to_uci(52 | (60 << 6) | (2 << 12)) == "e7e8n"
+    assert [m.uci() for m in g.board.move_stack][-2:] == ["g8f6", "e1g1"]
+    c = g.get_copy()
+    assert c.move("f8c5") and len(c) == 8 and len(g) == 7               # deep copy
+
+
+def test_results():
+    def res(fen):
+        return OracleGame(board=board_from_fen(fen)).get_result()
+    assert res("7k/6Q1/6K1/8/8/8/8/8 b - - 0 1") == 1                    # white mates
+    assert res("8/8/8/8/8/6k1/6q1/7K w - - 0 1") == -1                   # black mates
+    assert res("7k/5Q2/6K1/8/8/8/8/8 b - - 0 1") == 0                    # stalemate
+    assert res("8/8/8/4k3/8/8/4K3/7B w - - 0 1") == 0                    # K+B v K
+    assert res("8/8/8/4k3/8/8/4K3/6NN w - - 0 1") is None                # K+N+N v K
+    assert res("8/8/8/4k3/8/8/4K3/7R w - - 99 1") is None
+    assert res("8/8/8/4k3/8/8/4K3/7R w - - 100 1") == 0                  # fifty-move claim
+    assert res("7k/6Q1/6K1/8/8/8/8/8 b - - 100 1") == 1                  # mate beats the clock
+    g = OracleGame()
+    for _ in range(4):
+        assert g.get_result() is None
+        for u in ["g1f3", "g8f6", "f3g1", "f6g8"]:
+            g.move(u)
+    assert g.repetitions() == 5 and g.get_result() == 0                 # fivefold, not threefold
