@@ -179,7 +179,9 @@ def main():
         # ---- dominant kernel: the FxF 3x3 residual-block convolution at batch G (MFMA) ----
         conv = model.net.conv1[0]
         x = torch.randn((G, F, 8, 8), device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last)
-        conv_ms = event_time_ms(lambda: conv(x), 20)
+        # bias=None: exactly ONE kernel launch per call (MIOpen igemm_fwd_gtcx35_nhwc_fp16...), so
+        # the HIP-event average is that kernel's launch duration, comparable with rocprofv3 --stats
+        conv_ms = event_time_ms(lambda: torch.nn.functional.conv2d(x, conv.weight, None, padding=1), 50)
         conv_flops = 2.0 * 9 * F * F * 64 * G
         tower_ms = event_time_ms(lambda: model(eng.planes_s2), 10)
         tower_flops = 2.0 * model.macs_per_eval() * G

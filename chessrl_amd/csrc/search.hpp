@@ -585,7 +585,9 @@ __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, in
         const int c = d.e_child[e] & CHILD_NONE;
         visits[o] = d.e_visits[e];
         values[o] = d.e_value[e];
-        priors[o] = d.e_prior[e];
+        // _update_prior runs only once the node is fully expanded (mctree.py:254-255); until
+        // then the reference's children still carry Node.prior = 1
+        priors[o] = m.nexp < m.nmoves ? 1.0f : d.e_prior[e];
         moves[o] = d.e_move[e];
         replies[o] = d.meta[nb + c].has_s2 ? d.n_reply[nb + c] : NO_MOVE;
     }
