@@ -2,6 +2,7 @@
 // C-ABI declared in include/chessrl_hip.h.  gfx950 only; no torch types cross this boundary.
 #include "../../include/chessrl_hip.h"
 #include "search.hpp"
+#include "tower.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -446,6 +447,34 @@ int crl_counters(crl_ctx *ctx, uint64_t *out6)
     for (int k = 0; k < CNT_N; k++) out6[k] = 0;
     for (int g = 0; g < ctx->d.G; g++)
         for (int k = 0; k < CNT_N; k++) out6[k] += h[(size_t)g * CNT_N + k];
+    return CRL_OK;
+}
+
+// ---- tower seam (model.py) -------------------------------------------------------------------
+int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const void *dev_wtiles_f16,
+                         const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
+                         const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32)
+{
+    if (!dev_planes_f16 || !dev_wtiles_f16 || !dev_bias_f32 || (!dev_out_f32 && !dev_head_out_f32) ||
+        (dev_head_out_f32 && (!dev_head_w_f32 || !dev_head_b_f32)) || n_boards < 4 ||
+        n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
+        1 + 2 * n_blocks > crl_tower::MAX_CONVS)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk128_forward: bad argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)crl_tower::k_trunk128,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, crl_tower::LDS_BYTES);
+        if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(crl_tower::k_trunk128, dim3(n_boards / crl_tower::BOARDS_PER_WG), dim3(512),
+                       crl_tower::LDS_BYTES, (hipStream_t)hip_stream,
+                       (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,
+                       (const float *)dev_bias_f32, (float *)dev_out_f32, n_blocks,
+                       (const float *)dev_head_w_f32, (const float *)dev_head_b_f32,
+                       (float *)dev_head_out_f32);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
 }
 

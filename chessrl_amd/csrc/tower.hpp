@@ -1,0 +1,307 @@
+// tower.hpp -- fused residual trunk of the policy/value tower for gfx950 (MFMA, fp16 in,
+// fp32 accumulate), F = 128 filters.
+//
+// Replaces the trunk of ChessModel (/root/reference/src/chessrl/model.py:33-37,111-122: stem
+// Conv3x3 + N x [Conv3x3-BN-ReLU-Conv3x3-BN-add-ReLU]) for inference.  BatchNorm is folded into
+// the convolution weights/bias on the host (chessrl_amd/model.py).
+//
+// MI355X design.  A chess board is 8x8 = 64 positions: with NHWC activations a whole board is a
+// 64 x 128 fp16 tile of 16 KiB, so a workgroup keeps the activations of its 4 boards (M = 256
+// GEMM rows) resident in LDS for the ENTIRE tower: no activation ever goes back to HBM between
+// layers.  Per workgroup:
+//   * 8 waves (2 per SIMD); wave w owns board w/2 and output channels [64*(w&1), +64): a
+//     64(pos) x 64(ch) fp32 accumulator tile = 2x2 MFMA 32x32x16 tiles (64 VGPRs), plus the
+//     fp32 RESIDUAL STREAM of the same tile in another 64 VGPRs -- the skip connection never
+//     leaves registers and is never rounded to fp16;
+//   * the 3x3 convolution is an implicit GEMM over 9 taps x 128 channels.  The activation
+//     operand of tap (dy,dx) is read straight from the LDS-resident board at row p + 8dy + dx;
+//     off-board neighbours read a 256-byte row of zeros (one v_cndmask on the ADDRESS per read);
+//   * weights stream global -> LDS with global_load_lds (16 B/lane, no VGPR round trip) as
+//     16-KiB tiles [128 out-ch][64 in-ch] through a 3-buffer ring, two tiles in flight; ONE
+//     raw s_barrier per K-step with a counted s_waitcnt vmcnt(2); the stream runs across layer
+//     boundaries (weights do not depend on activations), so the MFMA pipe only drains at the
+//     single extra barrier per layer that separates the last read of the activation buffer
+//     from the epilogue's in-place rewrite;
+//   * the product is computed transposed (D[out-ch][pos] = W . X^T): a lane then holds 4
+//     CONSECUTIVE channels of one position per accumulator quad, so the epilogue (bias, residual
+//     add, ReLU, fp16 pack) writes 8-byte words back into the NHWC LDS image;
+//   * LDS images are XOR-swizzled in 16-B chunks (activations: chunk ^ (pos & 15); weight tile:
+//     chunk ^ ((row >> 1) & 7), applied on the SOURCE address of the LDS-DMA) so that every
+//     ds_read_b128 lane group covers all 64 banks.
+// The heads (1x1 convs + dense layers, < 1 % of the FLOPs) stay in PyTorch and read the fp32
+// trunk output.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crl_tower {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BOARDS_PER_WG = 4;
+constexpr int CH = 128;                       // channels in and out of every trunk conv
+constexpr int ROW_BYTES = CH * 2;             // one position, fp16
+constexpr int BOARD_BYTES = 64 * ROW_BYTES;   // 16 KiB
+constexpr int ACT_BYTES = BOARDS_PER_WG * BOARD_BYTES;   // 64 KiB
+constexpr int ZERO_OFF = ACT_BYTES;           // 256 B of zeros
+constexpr int MAX_CONVS = 41;                 // stem + 2 * 20 blocks
+constexpr int BIAS_OFF = ZERO_OFF + 256;      // float [MAX_CONVS][128]
+constexpr int WRING_OFF = ((BIAS_OFF + MAX_CONVS * CH * 4 + 1023) / 1024) * 1024;
+constexpr int WTILE_BYTES = CH * 64 * 2;      // [128 out][64 in] fp16 = 16 KiB
+constexpr int WRING_BUFS = 3;
+constexpr int LDS_BYTES = WRING_OFF + WRING_BUFS * WTILE_BYTES;
+constexpr int KSTEPS_PER_CONV = 9 * (CH / 64);   // 18
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+__device__ inline half8 lds_read16(const lds_byte *base, int off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) half8 *>(base + off);
+}
+
+// stage weight tile `t` into ring buffer t % 3: 2 x 16 B per thread, LDS image linear per wave
+// instruction, XOR swizzle applied to the per-lane SOURCE address
+__device__ inline void stage_wtile(const unsigned char *wts, lds_byte *lds, int t, int tid)
+{
+    const unsigned char *src = wts + (size_t)t * WTILE_BYTES;
+    lds_byte *dst = lds + WRING_OFF + (t % WRING_BUFS) * WTILE_BYTES;
+    const int wave_base = tid & ~63;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int idx = j * 512 + tid;                 // 16-B slot in the tile image
+        const int row = idx >> 3, phys = idx & 7;
+        const int chunk = phys ^ ((row >> 1) & 7);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(src + row * 128 + chunk * 16),
+            (__attribute__((address_space(3))) void *)(dst + (j * 512 + wave_base) * 16), 16, 0, 0);
+    }
+}
+
+// One workgroup = 4 boards through stem + n_blocks residual blocks.
+//   planes : fp16 [n_boards][64][128] (NHWC, channel 127 zero pad)
+//   wts    : fp16 tiles, consumption order [conv][tap][kc][128 out][64 in]
+//   bias   : f32 [n_convs][128]
+//   out    : f32 [n_boards][64][128]  trunk output (after the last block's ReLU), or nullptr
+//   head_w : f32 [3][128], head_b f32 [3]: folded 1x1 head convs (policy ch 0,1; value ch 2)
+//   head_out: f32 [n_boards][192] = ReLU(head convs): 128 policy (pos*2+ch) + 64 value, or nullptr
+__global__ __launch_bounds__(512, 2) void k_trunk128(const unsigned char *__restrict__ planes,
+                                                      const unsigned char *__restrict__ wts,
+                                                      const float *__restrict__ bias,
+                                                      float *__restrict__ out, int n_blocks,
+                                                      const float *__restrict__ head_w,
+                                                      const float *__restrict__ head_b,
+                                                      float *__restrict__ head_out)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    lds_byte *lds = (lds_byte *)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int board = wave >> 1, nh = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_convs = 1 + 2 * n_blocks;
+    const int n_tiles = n_convs * KSTEPS_PER_CONV;
+    const size_t wg_board0 = (size_t)blockIdx.x * BOARDS_PER_WG;
+
+    // ---- weight stream prologue: two tiles in flight -------------------------------------------
+    stage_wtile(wts, lds, 0, tid);
+    stage_wtile(wts, lds, 1, tid);
+
+    // ---- planes -> swizzled LDS image; zero row; biases ------------------------------------------
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int q = i * 512 + tid;               // 16-B chunk of the 64-KiB block
+            const int p = (q >> 4) & 63, c = q & 15, b = q >> 10;
+            u32x4 v = src[q];
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
+                lds + b * BOARD_BYTES + p * ROW_BYTES + ((c ^ (p & 15)) << 4)) = v;
+        }
+        if (tid < 16)
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + ZERO_OFF + tid * 16) =
+                u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < n_convs * CH; i += 512)
+            *reinterpret_cast<__attribute__((address_space(3))) float *>(lds + BIAS_OFF + i * 4) = bias[i];
+    }
+
+    // per-lane geometry of the two position tiles (mt = 0,1): p = 32*mt + r
+    int px[2], py[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) { const int p = 32 * mt + r; px[mt] = p & 7; py[mt] = p >> 3; }
+    // weight fragment rows (out-channels) of the two channel tiles (nt = 0,1)
+    int wrow_off[2], wrow_swz[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        const int o = 64 * nh + 32 * nt + r;
+        wrow_off[nt] = o * 128;
+        wrow_swz[nt] = (o >> 1) & 7;
+    }
+
+    f32x16 res[2][2];                                   // fp32 residual stream, [mt][nt]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) res[a][b][i] = 0.f;
+
+    int t = 0;                                          // weight tile counter (consumption order)
+    for (int conv = 0; conv < n_convs; conv++) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
+
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int abase[2], aswz[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                const int yy = py[mt] + dy, xx = px[mt] + dx;
+                const bool ok = ((unsigned)yy < 8u) && ((unsigned)xx < 8u);
+                const int pp = yy * 8 + xx;
+                abase[mt] = ok ? board * BOARD_BYTES + pp * ROW_BYTES : ZERO_OFF;
+                aswz[mt] = ok ? (pp & 15) : 0;
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; kc++) {
+                // ---- one K-step: tile t is in ring buffer t % 3 -----------------------------------
+                // my part of tile t has landed (tile t+1 may still be in flight); my LDS writes
+                // (epilogue of the previous layer) have completed
+                if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < n_tiles) stage_wtile(wts, lds, t + 2, tid);
+                const lds_byte *wbuf = lds + WRING_OFF + (t % WRING_BUFS) * WTILE_BYTES;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    half8 xf[2], wf[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+                        xf[mt] = lds_read16(lds, abase[mt] + (((kc * 8 + 2 * s + h) ^ aswz[mt]) << 4));
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        wf[nt] = lds_read16(wbuf, wrow_off[nt] + (((2 * s + h) ^ wrow_swz[nt]) << 4));
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                        for (int nt = 0; nt < 2; nt++)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+                }
+                t++;
+            }
+        }
+
+        // ---- epilogue: every wave has finished reading the activation buffer ----------------------
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool is_stem = conv == 0;
+        const bool is_conv2 = !is_stem && ((conv & 1) == 0);     // convs 1,3,5.. = conv1; 2,4,.. = conv2
+        const bool keep_res = !is_stem && !is_conv2;             // conv1 leaves the skip stream alone
+        const float relu_floor = is_stem ? -__builtin_inff() : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int p = 32 * mt + r;
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int o0 = 64 * nh + 32 * nt + 8 * g + 4 * h;     // 4 consecutive channels
+                    const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
+                        lds + BIAS_OFF + (conv * CH + o0) * 4);
+                    half4 o16;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // wave-uniform selects instead of branches: stem = bias only (no BN, no
+                        // activation, model.py:33-34); conv1 = ReLU; conv2 = +skip, ReLU
+                        const float skip = is_conv2 ? res[mt][nt][4 * g + j] : 0.f;
+                        float v = (acc[mt][nt][4 * g + j] + bv[j]) + skip;
+                        v = fmaxf(v, relu_floor);
+                        res[mt][nt][4 * g + j] = keep_res ? res[mt][nt][4 * g + j] : v;
+                        o16[j] = (_Float16)v;
+                    }
+                    const int chunk = (o0 >> 3) ^ (p & 15);
+                    *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
+                        lds + board * BOARD_BYTES + p * ROW_BYTES + (chunk << 4) + 8 * h) = o16;
+                }
+            }
+        }
+        // the barrier at the top of the next K-step orders these writes before the next reads
+    }
+
+    // ---- optional trunk output: fp32 residual stream -> global [board][pos][ch] -----------------------
+    if (out) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int p = 32 * mt + r;
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int o0 = 64 * nh + 32 * nt + 8 * g + 4 * h;
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = res[mt][nt][4 * g + j];
+                    *reinterpret_cast<f32x4 *>(out + ((wg_board0 + board) * 64 + p) * CH + o0) = v;
+                }
+        }
+    }
+
+    // ---- head 1x1 convolutions (policy: 2 channels, value: 1; BN folded) + ReLU, in fp32 -----------
+    // model.py:40-42,51-55.  A position's 128 channels are spread over 2 waves x 2 lane halves:
+    // each lane reduces its 32 channels, the 4 partial sums meet in LDS (the activation buffer is
+    // dead now) and are added in a FIXED order (no float atomics: results are reproducible).
+    if (head_out) {
+        float part[2][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) part[mt][k] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int o0 = 64 * nh + 32 * nt + 8 * g + 4 * h;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(head_w + k * CH + o0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        part[0][k] += res[0][nt][4 * g + j] * wv[j];
+                        part[1][k] += res[1][nt][4 * g + j] * wv[j];
+                    }
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // last epilogue's LDS traffic is over
+        __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                scratch[(((board * 64 + 32 * mt + r) * 3) + k) * 4 + nh * 2 + h] = part[mt][k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int i = tid; i < BOARDS_PER_WG * 64 * 3; i += 512) {
+            const int k = i % 3, bp = i / 3;           // bp = board * 64 + position
+            const f32x4 c = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(scratch + i * 4);
+            const float v = (((c[0] + c[1]) + c[2]) + c[3]) + head_b[k];
+            // per board 192 floats: [0,128) = policy head in Keras Flatten order (pos*2 + ch),
+            // [128,192) = value head (pos): both dense layers read them without a gather
+            const size_t gb = wg_board0 + (bp >> 6);
+            const int pos = bp & 63;
+            head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
+        }
+    }
+}
+
+}  // namespace crl_tower

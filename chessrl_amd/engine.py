@@ -78,6 +78,10 @@ class LockstepEngine(object):
         self.ctx.close()
 
     def _eval_into(self, planes, pol_out, val_out):
+        fi = getattr(self.evaluator, "forward_into", None)
+        if fi is not None:                       # ChessModel: no extra copy of the 32 MB policy
+            fi(planes, pol_out, val_out)
+            return
         pol, val = self.evaluator(planes)
         pol_out.copy_(pol)
         if val_out is not None:

@@ -118,12 +118,19 @@ class Tower(nn.Module):
             fc.weight.copy_(torch.from_numpy(np.asarray(w[name + ".kernel"], np.float32)).t())
             fc.bias.copy_(torch.from_numpy(np.asarray(w[name + ".bias"], np.float32)))
 
-    def forward(self, x):
+    def trunk(self, x):
         x = self.stem(x)                                     # no BN / activation (model.py:33-34)
         for c1, c2 in zip(self.conv1, self.conv2):
             y = F.relu(c1(x))
             y = c2(y)
             x = F.relu(x + y)
+        return x
+
+    def forward(self, x):
+        return self.heads(self.trunk(x))
+
+    def heads(self, x):
+        """Policy and value heads on the trunk activations (B,F,8,8), in fp32."""
         b = x.shape[0]
         x = x.float()                                        # heads are tiny: run them in fp32
         p = F.relu(self.policy_conv(x)).permute(0, 2, 3, 1).reshape(b, 128)   # Keras Flatten (h,w,c)
@@ -151,13 +158,14 @@ class ChessModel(object):
     """
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
-                 dtype=torch.float16, seed=0):
+                 dtype=torch.float16, seed=0, fused=True):
         if compile_model:
             raise NotImplementedError("training is out of scope of the self-play simulation path")
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
         self.dtype = dtype
+        self.want_fused = fused
         if isinstance(weights, str):
             weights = dict(np.load(weights))
         if weights is None:
@@ -171,6 +179,82 @@ class ChessModel(object):
         net.load_keras_dict(weights)
         self.net = net.cast_for_inference(self.device, self.dtype)
         self.blocks, self.filters = blocks, filters
+        # the hand-written fused MFMA trunk (csrc/tower.hpp) covers 128 filters in fp16
+        self.fused = bool(self.want_fused and filters == 128 and self.dtype == torch.float16
+                          and 1 + 2 * blocks <= 41)
+        if self.fused:
+            self._pack_fused(weights)
+
+    def _pack_fused(self, w):
+        """BN-folded fp16 kernels as 16-KiB tiles in the kernel's consumption order
+        [conv][tap=ky*3+kx][in-ch/64][128 out][64 in]; biases f32 [conv][128]."""
+        names = [("stem", None)]
+        for i in range(self.blocks):
+            names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
+        tiles, biases = [], []
+        for conv, bn in names:
+            k, b = _fold(w, conv, bn)                          # OIHW fp32
+            if k.shape[1] < PAD_PLANES:
+                kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
+                kp[:, :k.shape[1]] = k
+                k = kp
+            t = k.permute(2, 3, 0, 1).reshape(9, 128, 2, 64).permute(0, 2, 1, 3)   # [tap][kc][o][c]
+            tiles.append(t.contiguous())
+            biases.append(b)
+        self._wtiles = torch.stack(tiles).to(self.device, torch.float16).contiguous()
+        self._wbias = torch.stack(biases).to(self.device, torch.float32).contiguous()
+        kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][128][1][1]
+        kv, bv = _fold(w, "value.conv", "value.bn")            # [1][128][1][1]
+        self._head_w = torch.cat([kp.reshape(2, 128), kv.reshape(1, 128)]).to(self.device).contiguous()
+        self._head_b = torch.cat([bp, bv]).to(self.device).contiguous()
+        self._pad_in = None
+
+    def _run_fused(self, planes, want_trunk=False):
+        """One launch of the fused trunk kernel.  Returns (trunk fp32 [B,8,8,128] or None,
+        head activations fp32 [B,192] = ReLU(1x1 head convs): 128 policy + 64 value)."""
+        import ctypes
+        from . import _lib
+        b = planes.shape[0]
+        bp = (b + 3) // 4 * 4
+        if bp != b or not planes.is_contiguous() or planes.dtype != torch.float16:
+            if self._pad_in is None or self._pad_in.shape[0] != bp:
+                self._pad_in = torch.zeros((bp, 8, 8, PAD_PLANES), dtype=torch.float16, device=self.device)
+            self._pad_in[:b].copy_(planes)
+            planes = self._pad_in
+        trunk = torch.empty((bp, 8, 8, 128), dtype=torch.float32, device=self.device) if want_trunk else None
+        heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
+        rc = _lib.lib().crl_trunk128_forward(
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+            ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(self._wtiles.data_ptr()),
+            ctypes.c_void_p(self._wbias.data_ptr()),
+            ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
+            ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
+            ctypes.c_void_p(heads.data_ptr()))
+        if rc != 0:
+            raise _lib.HipLibraryError("crl_trunk128_forward failed (%d)" % rc)
+        return (trunk[:b] if want_trunk else None), heads[:b]
+
+    def _forward_fused(self, planes, pol_out=None, val_out=None):
+        """Fused trunk + head convs in the HIP kernel; the dense layers (model.py:44-48,56-61)
+        are three small fp32 GEMMs, written straight into the caller's buffers when given."""
+        _, hp = self._run_fused(planes)
+        n = self.net
+        p = torch.softmax(n.policy_fc(hp[:, :128]), dim=-1, out=pol_out)
+        v = F.relu(n.value_fc1(hp[:, 128:]))
+        z = n.value_fc2(v)[:, 0]
+        v = torch.tanh(z, out=val_out) if val_out is not None else torch.tanh(z)
+        return p, v
+
+    @torch.no_grad()
+    def forward_into(self, planes, pol_out, val_out):
+        """Evaluate and write policy [B,1968] / value [B] into existing fp32 tensors."""
+        if self.fused:
+            self._forward_fused(planes, pol_out, val_out)
+        else:
+            p, v = self(planes)
+            pol_out.copy_(p)
+            if val_out is not None:
+                val_out.copy_(v)
 
     def load_weights(self, weights_path):
         self.load_dict(dict(np.load(weights_path)))
@@ -180,6 +264,8 @@ class ChessModel(object):
 
     @torch.no_grad()
     def __call__(self, planes):
+        if self.fused:
+            return self._forward_fused(planes)
         x = planes.to(self.dtype).permute(0, 3, 1, 2)         # NHWC memory viewed as NCHW
         return self.net(x)
 

@@ -144,6 +144,22 @@ int  crl_advance(crl_ctx *ctx, const int32_t *chosen /*G*/, uint16_t *bm, uint16
  * [4] tower evaluations consumed, [5] terminal leaves hit. */
 int  crl_counters(crl_ctx *ctx, uint64_t *out6);
 
+/* ---- tower seam (model.py) -------------------------------------------------------------- */
+/* Residual trunk of ChessModel (model.py:33-37,111-122: stem conv + n_blocks residual blocks,
+ * BatchNorm folded) for 128 filters as ONE fused MFMA kernel, plus the three 1x1 head
+ * convolutions with their BN + ReLU (model.py:40-42,51-55).  fp16 NHWC planes
+ * [n_boards][8][8][128] in.  dev_wtiles_f16 holds the folded fp16 kernels as 16-KiB tiles in
+ * consumption order [conv][tap][in-ch/64][128 out][64 in]; dev_bias_f32 is [1+2*n_blocks][128].
+ * Outputs (either may be NULL): dev_out_f32 = fp32 trunk activations [n_boards][8][8][128];
+ * dev_head_out_f32 = [n_boards][192] floats after ReLU: [0,128) the policy head in Keras Flatten
+ * order (position*2 + channel), [128,192) the value head; from dev_head_w_f32 [3][128] and
+ * dev_head_b_f32 [3].  n_boards % 4 == 0.
+ * Stateless: needs no crl_ctx. */
+int  crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const void *dev_wtiles_f16,
+                          const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
+                          const void *dev_head_w_f32, const void *dev_head_b_f32,
+                          void *dev_head_out_f32);
+
 #ifdef __cplusplus
 }
 #endif
