@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-fused", action="store_true", help="PyTorch-ROCm trunk instead of the HIP kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -135,7 +136,7 @@ def main():
     from chessrl_amd.selfplay import SelfPlayRunner
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
     model = ChessModel(blocks=a.blocks, filters=a.filters, device="cuda:%d" % local, dtype=tdt,
-                       seed=a.seed)
+                       seed=a.seed, fused=not a.no_fused)
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
                          device=local, use_graph=not a.no_graph, max_plies=2048)
 
@@ -176,20 +177,29 @@ def main():
         nodes = max(1, d["nodes"])
         depth = d["depth_sum"] / max(1, d["sims"])
         branch = d["branch_sum"] / nodes
-        # ---- dominant kernel: the FxF 3x3 residual-block convolution at batch G (MFMA) ----
-        conv = model.net.conv1[0]
-        x = torch.randn((G, F, 8, 8), device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last)
-        # bias=None: exactly ONE kernel launch per call (MIOpen igemm_fwd_gtcx35_nhwc_fp16...), so
-        # the HIP-event average is that kernel's launch duration, comparable with rocprofv3 --stats
-        conv_ms = event_time_ms(lambda: torch.nn.functional.conv2d(x, conv.weight, None, padding=1), 50)
-        conv_flops = 2.0 * 9 * F * F * 64 * G
-        tower_ms = event_time_ms(lambda: model(eng.planes_s2), 10)
+        # ---- dominant kernel (MFMA-bound) ----------------------------------------------------
+        tower_ms = event_time_ms(lambda: model.forward_into(eng.planes_s2, eng.pol_s2, eng.val_s2), 20)
         tower_flops = 2.0 * model.macs_per_eval() * G
         peak = MFMA_PEAK_TFLOPS[a.dtype]
-        roof = {"bound": "mfma", "kernel": "3x3 conv %d->%d, batch %d x 8x8 (PyTorch-ROCm)" % (F, F, G),
-                "achieved": conv_flops / conv_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
-                "frac": conv_flops / conv_ms / 1e9 / peak, "traffic": None,
-                "launch_ms": conv_ms, "flops_per_launch": conv_flops,
+        if model.fused:
+            # crl_tower::k_trunk128 -- the hand-written fused trunk: ONE launch per tower forward.
+            # Algorithmic FLOPs per launch = 2 x (stem 73152 F + blocks 1152 F^2 B + head convs
+            # 192 F) MACs per board x G boards.
+            k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
+            k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
+            k_name = "crl_tower::k_trunk128 (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
+        else:
+            # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
+            # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats
+            conv = model.net.conv1[0]
+            x = torch.randn((G, F, 8, 8), device=dev, dtype=tdt).contiguous(memory_format=torch.channels_last)
+            k_ms = event_time_ms(lambda: torch.nn.functional.conv2d(x, conv.weight, None, padding=1), 50)
+            k_flops = 2.0 * 9 * F * F * 64 * G
+            k_name = "3x3 conv %d->%d, batch %d x 8x8 (PyTorch-ROCm / MIOpen igemm)" % (F, F, G)
+        roof = {"bound": "mfma", "kernel": k_name,
+                "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
+                "frac": k_flops / k_ms / 1e9 / peak, "traffic": None,
+                "launch_ms": k_ms, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}
         # ---- hand-written HIP search kernels (HBM-bound): select+expand and reply -----------
@@ -213,7 +223,7 @@ def main():
                                    "%d-block/%d-filter random-init tower, standard start position, "
                                    "Dirichlet noise on" % (G, a.sims, B, F),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
-                       "hipgraph": not a.no_graph, "parallelism": "games sharded, no collective on the hot path"},
+                       "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused), "parallelism": "games sharded, no collective on the hot path"},
             "moves_per_sec": total_sims / max_dt / a.sims,
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libchessrl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp", "tower.hpp")]
+           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp", "tower.hpp", "tower_pipe.hpp")]
 HEADER = os.path.join(_ROOT, "include", "chessrl_hip.h")
 
 MAX_MOVES = 256

@@ -3,8 +3,10 @@
 #include "../../include/chessrl_hip.h"
 #include "search.hpp"
 #include "tower.hpp"
+#include "tower_pipe.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -460,15 +462,33 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
         1 + 2 * n_blocks > crl_tower::MAX_CONVS)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk128_forward: bad argument");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)crl_tower::k_trunk128,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, crl_tower::LDS_BYTES);
-        if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
-        attr_set = true;
+    // CRL_TRUNK_VARIANT selects a tuning/diagnostic build of the kernel (unset/0 = production)
+    const char *ev = getenv("CRL_TRUNK_VARIANT");
+    const int var = ev ? atoi(ev) : 0;
+    typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
+                           const float *, const float *, float *);
+    kern_t kern = crl_tower::k_trunk128_pipe<1>;       // production: pinned pipeline, distance 1
+    int lds_bytes = crl_tower::P2_LDS_BYTES;
+    switch (var) {
+    case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 3: kern = crl_tower::k_trunk128<3>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = crl_tower::LDS_BYTES; break;   // unpipelined baseline
+    case 6: kern = crl_tower::k_trunk128_pipe<2>; break;                                   // prefetch distance 2
+    case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 103: kern = crl_tower::k_trunk128<103>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 104: kern = crl_tower::k_trunk128<104>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 105: kern = crl_tower::k_trunk128<105>; lds_bytes = crl_tower::LDS_BYTES; break;
+    case 106: kern = crl_tower::k_trunk128<106>; lds_bytes = crl_tower::LDS_BYTES; break;
+    default: break;
     }
-    hipLaunchKernelGGL(crl_tower::k_trunk128, dim3(n_boards / crl_tower::BOARDS_PER_WG), dim3(512),
-                       crl_tower::LDS_BYTES, (hipStream_t)hip_stream,
+    hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        lds_bytes);
+    if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+    hipLaunchKernelGGL(kern, dim3(n_boards / crl_tower::BOARDS_PER_WG), dim3(512),
+                       lds_bytes, (hipStream_t)hip_stream,
                        (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,
                        (const float *)dev_bias_f32, (float *)dev_out_f32, n_blocks,
                        (const float *)dev_head_w_f32, (const float *)dev_head_b_f32,

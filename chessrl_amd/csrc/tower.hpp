@@ -89,6 +89,10 @@ __device__ inline void stage_wtile(const unsigned char *wts, lds_byte *lds, int 
 //   out    : f32 [n_boards][64][128]  trunk output (after the last block's ReLU), or nullptr
 //   head_w : f32 [3][128], head_b f32 [3]: folded 1x1 head convs (policy ch 0,1; value ch 2)
 //   head_out: f32 [n_boards][192] = ReLU(head convs): 128 policy (pos*2+ch) + 64 value, or nullptr
+// VAR: 0 = production.  100.. = timing-only diagnostics (WRONG results): 100 no K-step barrier,
+// 101 no weight staging in the loop, 102 weight fragments read once, 103 activation fragments
+// read once.  1.. = tuning variants (correct results).
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void k_trunk128(const unsigned char *__restrict__ planes,
                                                       const unsigned char *__restrict__ wts,
                                                       const float *__restrict__ bias,
@@ -175,26 +179,68 @@ __global__ __launch_bounds__(512, 2) void k_trunk128(const unsigned char *__rest
                 // ---- one K-step: tile t is in ring buffer t % 3 -----------------------------------
                 // my part of tile t has landed (tile t+1 may still be in flight); my LDS writes
                 // (epilogue of the previous layer) have completed
-                if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                half8 xfa[4][2], wfa[4][2];
+                if (VAR == 3) {
+                    // the activation buffer is stable for the whole layer: its fragments need not
+                    // wait for the weight tile's barrier
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int mt = 0; mt < 2; mt++)
+                            xfa[s][mt] = lds_read16(lds, abase[mt] + (((kc * 8 + 2 * s + h) ^ aswz[mt]) << 4));
+                    if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    if (t + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                if (VAR != 100 && VAR != 104 && VAR != 105 && VAR != 106) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 2 < n_tiles) stage_wtile(wts, lds, t + 2, tid);
+                if (VAR != 101 && VAR != 104 && VAR != 105 && VAR != 106 && t + 2 < n_tiles) stage_wtile(wts, lds, t + 2, tid);
                 const lds_byte *wbuf = lds + WRING_OFF + (t % WRING_BUFS) * WTILE_BYTES;
+                if (VAR == 2 || VAR == 3) {
+                    if (VAR == 2) {
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+#pragma unroll
+                            for (int mt = 0; mt < 2; mt++)
+                                xfa[s][mt] = lds_read16(lds, abase[mt] + (((kc * 8 + 2 * s + h) ^ aswz[mt]) << 4));
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int nt = 0; nt < 2; nt++)
+                            wfa[s][nt] = lds_read16(wbuf, wrow_off[nt] + (((2 * s + h) ^ wrow_swz[nt]) << 4));
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                            for (int nt = 0; nt < 2; nt++)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfa[s][nt], xfa[s][mt], acc[mt][nt], 0, 0, 0);
+                    t++;
+                    continue;
+                }
+                half8 xf[2], wf[2];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    half8 xf[2], wf[2];
+                    if ((VAR != 103 && VAR != 104 && VAR != 105) || (s == 0 && (VAR != 105 || t == 0))) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; mt++)
-                        xf[mt] = lds_read16(lds, abase[mt] + (((kc * 8 + 2 * s + h) ^ aswz[mt]) << 4));
+                        for (int mt = 0; mt < 2; mt++)
+                            xf[mt] = lds_read16(lds, abase[mt] + (((kc * 8 + 2 * s + h) ^ aswz[mt]) << 4));
+                    }
+                    if ((VAR != 102 && VAR != 104 && VAR != 105) || (s == 0 && (VAR != 105 || t == 0))) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++)
-                        wf[nt] = lds_read16(wbuf, wrow_off[nt] + (((2 * s + h) ^ wrow_swz[nt]) << 4));
+                        for (int nt = 0; nt < 2; nt++)
+                            wf[nt] = lds_read16(wbuf, wrow_off[nt] + (((2 * s + h) ^ wrow_swz[nt]) << 4));
+                    }
+                    if (VAR == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                         for (int nt = 0; nt < 2; nt++)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+                    if (VAR == 1) __builtin_amdgcn_s_setprio(0);
                 }
                 t++;
             }
@@ -236,6 +282,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128(const unsigned char *__rest
             }
         }
         // the barrier at the top of the next K-step orders these writes before the next reads
+        if (VAR == 3) {                                 // ... unless activations are read before it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     // ---- optional trunk output: fp32 residual stream -> global [board][pos][ch] -----------------------

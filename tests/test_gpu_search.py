@@ -164,7 +164,10 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, rbn, dtype):
     assert dp <= 1e-3 and dv <= vtol, (dp, dv)
     # the engine's in-place path and the Keras-style predict() surface give the same numbers
     model.forward_into(eng.planes_s1, eng.pol_s1, eng.val_s2)
-    assert torch.equal(eng.pol_s1, pol) and torch.equal(eng.val_s2, val)
+    if model.fused:       # the HIP trunk is run-to-run deterministic; MIOpen's solver choice is not
+        assert torch.equal(eng.pol_s1, pol) and torch.equal(eng.val_s2, val)
+    else:
+        assert (eng.pol_s1 - pol).abs().max() <= 1e-3 and (eng.val_s2 - val).abs().max() <= vtol
     kp, kv = model.predict(planes)
     assert np.abs(kp - epol.numpy()).max() <= 1e-3 and np.abs(kv[:, 0] - eval_.numpy()).max() <= vtol
     assert kp.shape == (30, 1968) and kv.shape == (30, 1)
