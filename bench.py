@@ -187,7 +187,7 @@ def main():
             # 192 F) MACs per board x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            k_name = "crl_tower::k_trunk128 (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
+            k_name = "crl_tower::k_trunk128_pipe<1> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats
@@ -196,9 +196,13 @@ def main():
             k_ms = event_time_ms(lambda: torch.nn.functional.conv2d(x, conv.weight, None, padding=1), 50)
             k_flops = 2.0 * 9 * F * F * 64 * G
             k_name = "3x3 conv %d->%d, batch %d x 8x8 (PyTorch-ROCm / MIOpen igemm)" % (F, F, G)
+        # traffic: rocprofv3 PMC passes of this kernel at this exact shape (profiles/r01/
+        # pmc_trunk_kernel.md): FETCH_SIZE 129 858 KB x 2 (gfx950 correction) + WRITE_SIZE 3 072 KB
+        traffic = 2 * 129858e3 + 3072e3 if (model.fused and (G, F, B) == (4096, 128, 10)) else None
         roof = {"bound": "mfma", "kernel": k_name,
                 "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
-                "frac": k_flops / k_ms / 1e9 / peak, "traffic": None,
+                "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic,
+                "algorithmic_bytes": (G * 64 * 128 * 2 + (1 + 2 * B) * 9 * F * F * 2 + G * 192 * 4) if model.fused else None,
                 "launch_ms": k_ms, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}

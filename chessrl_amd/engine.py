@@ -41,6 +41,39 @@ def compute_policy(visits, root_visits, nb_moves, noise=True, rng=None):
     return policy
 
 
+def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None):
+    """``np.argmax(compute_policy(...))`` for every game at once (-1 where nchild == 0).
+
+    Same arithmetic as ``compute_policy`` element for element (numpy's array ``power`` and
+    division are the scalar ones applied per element), so the chosen child is identical; only
+    the per-game Dirichlet draw stays a loop because every game owns its random stream.
+    ``visits`` [G, >=max(nchild)] int, children order; ``rngs`` one generator per game (or None
+    for the global ``np.random`` stream, drawn in game order).
+    """
+    G = len(nchild)
+    nchild = np.asarray(nchild)
+    plies_f = np.asarray(plies, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tau = np.where(plies_f >= 30, plies_f / (1 + np.power(plies_f, 1.3)), 1.0)
+        inv_tau = 1 / tau
+        w = int(nchild.max()) if G else 0
+        pol = (np.power(np.asarray(visits)[:, :w].astype(np.float64), inv_tau[:, None]) /
+               np.power(np.asarray(root_visits, dtype=np.float64), inv_tau)[:, None])
+    chosen = np.full(G, -1, dtype=np.int32)
+    cols = np.arange(w)
+    if noise:
+        for g in range(G):
+            n = int(nchild[g])
+            if n:
+                src = rngs[g] if rngs is not None else np.random
+                chosen[g] = int(np.argmax((1 - 0.25) * pol[g, :n] + src.dirichlet([0.03] * n)))
+    else:
+        live = nchild > 0
+        masked = np.where(cols[None, :] < nchild[:, None], pol, -np.inf)
+        chosen[live] = np.argmax(masked[live], axis=1)
+    return chosen
+
+
 class LockstepEngine(object):
     """G games x one search tree each on one GPU.
 

@@ -22,7 +22,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .engine import LockstepEngine, compute_policy
+from .engine import LockstepEngine, choose_children
 from .records import GameRecord
 
 log = logging.getLogger("chessrl_amd.selfplay")
@@ -133,16 +133,10 @@ class SelfPlayRunner(object):
         eng.ctx.sim_backup(eng.pol_s2.data_ptr(), eng.val_s2.data_ptr())
         rc = eng.ctx.root_children(("nchild", "visits", "root_visits"))
         _, plies, _ = eng.ctx.records(with_moves=False)
-        chosen = np.full(self.G, -1, dtype=np.int32)
-        live = 0
-        for g in range(self.G):
-            n = int(rc["nchild"][g])
-            if n == 0 or self.game_id[g] < 0:
-                continue
-            pol = compute_policy(rc["visits"][g, :n], rc["root_visits"][g], int(plies[g]),
-                                 noise=self.noise, rng=self.rngs[g])
-            chosen[g] = int(np.argmax(pol))
-            live += 1
+        nchild = np.where(self.game_id >= 0, rc["nchild"], 0)
+        chosen = choose_children(rc["visits"], nchild, rc["root_visits"], plies, noise=self.noise,
+                                 rngs=self.rngs)
+        live = int((chosen >= 0).sum())
         eng.advance(chosen)
         self.moves_played += live
         self.sims_run += live * self._sims_in_move

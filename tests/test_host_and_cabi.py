@@ -160,3 +160,29 @@ def test_encoder_oracle_known_answers():
     assert np.array_equal(s2[:, :, 14:28], s[:, :, 0:14])       # previous position in history slot 0
     assert not s2[:, :, 126].any() and s2[4, 4, 8] == 1 and s2[6, 4, 8] == 0
     assert np.array_equal(encoder_oracle.get_game_state(g, flipped=True), np.rot90(s2, k=2))
+
+
+def test_choose_children_equals_per_game_compute_policy():
+    """The batched move choice must pick exactly what argmax(compute_policy(...)) picks per game."""
+    from chessrl_amd.engine import choose_children, compute_policy
+    rng = np.random.default_rng(1)
+    G = 200
+    nchild = rng.integers(0, 45, size=G)
+    nchild[:5] = 0
+    visits = rng.integers(0, 30, size=(G, 256)).astype(np.int32)
+    plies = rng.integers(0, 300, size=G)
+    plies[:40] = rng.integers(25, 35, size=40)                 # around the tau switch at 30 plies
+    root = np.array([visits[g, :nchild[g]].sum() + 1 for g in range(G)])
+    for noise in (False, True):
+        rngs = [np.random.default_rng([7, g]) for g in range(G)]
+        got = choose_children(visits, nchild, root, plies, noise=noise, rngs=rngs)
+        rngs = [np.random.default_rng([7, g]) for g in range(G)]
+        for g in range(G):
+            if nchild[g] == 0:
+                assert got[g] == -1
+                continue
+            p = compute_policy(visits[g, :nchild[g]], root[g], int(plies[g]), noise=noise, rng=rngs[g])
+            assert got[g] == int(np.argmax(p)), (g, noise)
+            q = mcts_oracle.compute_policy(list(visits[g, :nchild[g]]), int(root[g]), int(plies[g]), noise=False)
+            if not noise:
+                assert got[g] == int(np.argmax(q))
