@@ -187,7 +187,7 @@ def main():
             # 192 F) MACs per board x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            k_name = "crl_tower::k_trunk128_pipe<1> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
+            k_name = "crl_tower::k_trunk128_pipe<1,1> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats
@@ -229,6 +229,9 @@ def main():
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused), "parallelism": "games sharded, no collective on the hot path"},
             "moves_per_sec": total_sims / max_dt / a.sims,
+            # games/hour: a random-init 10x128 net plays 190 moves (380 plies) per game on average
+            # (512 complete games, profiles/r01/game_length_c3net_50sims.json); assumption stated
+            "self_play_games_per_hour_est": total_sims / max_dt / a.sims / 190.0 * 3600.0,
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
             "roofline": roof, "roofline_tree": tree,

@@ -18,6 +18,7 @@
 //     the matrix pipe does not drain at K-step boundaries;
 //   * the only full drains left are the two barriers around each layer's epilogue.
 #pragma once
+#include <type_traits>
 #include "tower.hpp"
 
 namespace crl_tower {
@@ -25,12 +26,38 @@ namespace crl_tower {
 constexpr int PIPE_RING = 4;                       // weight tiles in the LDS ring
 struct Frags { half8 x[2]; half8 w[2]; };          // operands of one 16-channel sub-step
 
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ds_read_b128 the compiler does not see: hipcc's waitcnt pass answers a pinned prefetch with
+// `s_waitcnt lgkmcnt(0)` right behind the newest reads, i.e. it waits for the data of the NEXT
+// sub-step before issuing the MFMAs of the current one.  These reads are counted by hand
+// (`s_waitcnt lgkmcnt(4)` = the 4 newest may still be in flight).
+template <int OFF>
+__device__ __forceinline__ half8 lds_read16_asm(int addr)
+{
+    half8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 // padded activation image: row stride 272 B = 68 dwords -> 16 rows with distinct (row mod 16)
 // start on 16 different 4-bank groups, exactly what the XOR swizzle achieved
 constexpr int P2_AROW = ROW_BYTES + 16;
 constexpr int P2_ABOARD = 64 * P2_AROW;
-constexpr int P2_ZERO_OFF = BOARDS_PER_WG * P2_ABOARD;            // 288 B of zeros
-constexpr int P2_BIAS_OFF = P2_ZERO_OFF + 288;
+// off-board neighbours read zeros.  A single zero row would sit on ONE bank group and collide with
+// whichever in-board lane of the same ds_read_b128 group owns it (rocprofv3: 18 % of the LDS cycles
+// were conflicts); 16 zero rows laid out like board rows let an off-board lane read the row whose
+// bank group it would have used in-board: conflict-free by construction.
+constexpr int P2_ZERO_OFF = BOARDS_PER_WG * P2_ABOARD;
+constexpr int P2_ZERO_BYTES = 16 * P2_AROW;                         // 4352 B
+constexpr int P2_BIAS_OFF = P2_ZERO_OFF + P2_ZERO_BYTES;
 constexpr int P2_WRING_OFF = ((P2_BIAS_OFF + MAX_CONVS * CH * 4 + 1023) / 1024) * 1024;
 constexpr int P2_LDS_BYTES = P2_WRING_OFF + PIPE_RING * WTILE_BYTES;
 static_assert(P2_LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -53,7 +80,7 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
 
 
 
-template <int DIST>
+template <int DIST, int ASMRD>
 __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *__restrict__ planes,
                                                            const unsigned char *__restrict__ wts,
                                                            const float *__restrict__ bias,
@@ -86,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
                 lds + b * P2_ABOARD + p * P2_AROW + (c << 4)) = v;
         }
-        if (tid < 18)
+        if (tid < P2_ZERO_BYTES / 16)
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + P2_ZERO_OFF + tid * 16) =
                 u32x4{0u, 0u, 0u, 0u};
         for (int i = tid; i < n_convs * CH; i += 512)
@@ -134,7 +161,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int yy = py[mt] + dy, xx = px[mt] + dx;
             const bool ok = ((unsigned)yy < 8u) && ((unsigned)xx < 8u);
-            return (ok ? board * P2_ABOARD + (yy * 8 + xx) * P2_AROW : P2_ZERO_OFF) + h * 16;
+            const int pp = yy * 8 + xx;
+            return (ok ? board * P2_ABOARD + pp * P2_AROW : P2_ZERO_OFF + (pp & 15) * P2_AROW) + h * 16;
         };
         int ab[4][2];                                   // taps of the current block + first of the next
         auto fetch = [&](int blk, int i, bool next_blk, Frags &f) {
@@ -158,6 +186,60 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         Frags f0, f1, f2;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) ab[3][mt] = tap_base(0, mt);
+        if constexpr (ASMRD) {
+            // hand-counted variant (prefetch distance 1)
+            const int lds_base = (int)(size_t)lds;      // LDS byte address of the dynamic array
+            auto fetch_asm = [&](auto IC, int blk, bool next_blk, Frags &f) {
+                constexpr int i = decltype(IC)::value;
+                constexpr int kc = (i >> 2) & 1, s4 = i & 3;
+                f.x[0] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(lds_base + ab[next_blk ? 3 : (i >> 3)][0]);
+                f.x[1] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(lds_base + ab[next_blk ? 3 : (i >> 3)][1]);
+                const int wb = lds_base + P2_WRING_OFF +
+                               ((t_conv0 + 6 * blk + (i >> 2)) & (PIPE_RING - 1)) * WTILE_BYTES;
+                f.w[0] = lds_read16_asm<0>(wb + waddr[0][s4]);
+                f.w[1] = lds_read16_asm<0>(wb + waddr[1][s4]);
+            };
+            for (int blk = 0; blk < 3; blk++) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++) {
+                    ab[0][mt] = ab[3][mt];
+                    ab[1][mt] = tap_base(3 * blk + 1, mt);
+                    ab[2][mt] = tap_base(3 * blk + 2, mt);
+                    ab[3][mt] = tap_base(blk < 2 ? 3 * blk + 3 : 0, mt);
+                }
+                if (blk == 0) fetch_asm(std::integral_constant<int, 0>{}, 0, false, f0);
+                static_for<0, 24>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    if constexpr ((i & 3) == 2) {
+                        if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t + 3 < n_tiles) stage_wtile_p2(wts, lds, t + 3, tid);
+                    }
+                    constexpr bool wrap = i + 1 >= 24;
+                    bool issued = false;
+                    if (!wrap || blk < 2) {
+                        issued = true;
+                        if constexpr (wrap) {
+                            if constexpr (i % 2 == 0) fetch_asm(std::integral_constant<int, 0>{}, blk + 1, true, f1);
+                            else fetch_asm(std::integral_constant<int, 0>{}, blk + 1, true, f0);
+                        } else {
+                            if constexpr (i % 2 == 0) fetch_asm(std::integral_constant<int, i + 1>{}, blk, false, f1);
+                            else fetch_asm(std::integral_constant<int, i + 1>{}, blk, false, f0);
+                        }
+                    }
+                    // operands of THIS sub-step have landed; the 4 reads just issued may be in flight
+                    if (issued) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (i % 2 == 0) mfma4(f0);
+                    else mfma4(f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr ((i & 3) == 3) t++;
+                });
+            }
+        } else {
         for (int blk = 0; blk < 3; blk++) {             // 3 blocks x 24 sub-steps (3 taps each)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
@@ -208,6 +290,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                 __builtin_amdgcn_sched_barrier(0);
                 if ((i & 3) == 3) t++;
             }
+        }
+
         }
 
         // ---- epilogue: every wave has finished reading the activation buffer ----------------------

@@ -240,6 +240,8 @@ class ChessModel(object):
         _, hp = self._run_fused(planes)
         n = self.net
         p = torch.softmax(n.policy_fc(hp[:, :128]), dim=-1, out=pol_out)
+        if pol_out is not None and val_out is None:
+            return p, None                       # S1 evaluations only choose the reply: no value head
         v = F.relu(n.value_fc1(hp[:, 128:]))
         z = n.value_fc2(v)[:, 0]
         v = torch.tanh(z, out=val_out) if val_out is not None else torch.tanh(z)
