@@ -97,3 +97,43 @@ def test_dropin_objects_match_oracle():
     assert bm == oagent.best_move(og, real_game=False, max_iters=40, noise=True)
     g.free()
     c.free()
+
+
+def test_dataset_roundtrip_and_reference_shaped_play_game(tmp_path):
+    """DatasetGame (dataset.py) on HIP-backed Games + the reference-shaped play_game loop."""
+    import random
+    from chessrl_amd import selfplay
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.dataset import DatasetGame
+    from chessrl_amd.game import Game
+    net = FakeNet(seed=31, prior_shift=30)
+    agent = Agent(True, model=net.to("cuda:0"))
+    random.seed(4)
+    np.random.seed(4)
+    gam = selfplay.play_game(agent, max_iters=3)            # complete game, 3 sims/move
+    random.seed(4)
+    np.random.seed(4)
+    og = mcts_oracle.play_game(mcts_oracle.OracleAgent(net), max_iters=3, noise=True)
+    assert gam.get_history()["moves"] == og.get_history()["moves"]
+    assert gam.get_result() == og.get_result() and gam.get_result() is not None
+    d = DatasetGame()
+    d.append(gam)
+    text = str(d)
+    d2 = DatasetGame()
+    d2.loads(text)
+    assert len(d2) == 1 and d2[0].get_history()["moves"] == gam.get_history()["moves"]
+    assert d2[0].get_result() == gam.get_result()
+    short = Game()                                          # augment a prefix: one Game copy per ply
+    for m in gam.get_history()["moves"][:12]:
+        assert short.move(m)
+    aug = d.augment_game(short)
+    assert len(aug) == 12 and aug[0]["game"].get_fen() == Game().get_fen()
+    assert aug[3]["next_move"] == gam.get_history()["moves"][3] and len(aug[3]["game"]) == 3
+    path = str(tmp_path / "gameplays.json")
+    d.save(path)
+    d.save(path)                                            # save() appends to what is on disk
+    d3 = DatasetGame()
+    d3.load(path)
+    assert len(d3) == 2
+    for g in aug:
+        g["game"].free()
