@@ -87,6 +87,80 @@ def test_search_matches_oracle(mode, shift, quant, sims, graph):
     eng.close()
 
 
+def test_search_on_long_games_with_high_halfmove_clocks():
+    """Roots 120-260 plies deep: large halfmove clocks, so the tree meets the fifty-move claim
+    (terminal nodes inside the tree) and runs the repetition scan over tree path + game ring."""
+    from chessrl_amd.engine import LockstepEngine
+    G, sims = 10, 120
+    rng = np.random.default_rng(77)
+    games = []
+    while len(games) < G:                      # shuffle pieces: prefer non-pawn, non-capturing moves
+        g = OracleGame()
+        want = 120 + 14 * len(games)
+        while len(g) < want and g.get_result() is None:
+            b = g.board_at(0)
+            occ = 0
+            for t in range(6):
+                occ |= int(b.bb[t])
+            lm = g.legal_move_ids()
+            quiet = [m for m in lm if not (int(b.bb[0]) >> (m & 63)) & 1 and not (occ >> ((m >> 6) & 63)) & 1]
+            pool = quiet if quiet and rng.random() < 0.97 else lm
+            g.move(move_to_uci(pool[int(rng.integers(len(pool)))]))
+        if g.get_result() is None:
+            games.append(g)
+    clocks = [(int(g.board_at(0).state) >> 12) & 255 for g in games]
+    assert max(clocks) >= 40
+    net = FakeNet(seed=41, prior_shift=31)
+    eng = LockstepEngine(net.to("cuda:0"), n_games=G, max_sims=sims)
+    eng.load_moves([move_ids(g) for g in games])
+    eng.search(sims)
+    rc = eng.root_children()
+    hits = eng.ctx.counters()["terminal_hits"]
+    for i, g in enumerate(games):
+        r = mcts_oracle.search(g, mcts_oracle.OracleAgent(net), sims, noise=False)
+        n = rc["nchild"][i]
+        assert list(rc["visits"][i, :n]) == r.visits, (i, len(g), clocks[i])
+        assert np.array_equal(rc["values"][i, :n].view(np.uint64),
+                              np.array(r.values, dtype=np.float64).view(np.uint64)), i
+    print("long-game search: clocks", clocks, "terminal hits", hits)
+    eng.close()
+
+
+def test_search_across_the_fifty_move_claim_and_mates():
+    """Set-up positions whose trees contain fifty-move claims, stalemates and checkmates after
+    our move (state = S1) and after the reply (state = S2)."""
+    from chessrl_amd.engine import LockstepEngine
+    from oracle.chess_oracle import board_from_fen, board_to_array
+    fens = ["8/8/8/4k3/8/8/4K3/7R w - - 96 80",          # claims at clock 100 two plies down
+            "8/8/8/4k3/8/8/4K3/7R b - - 97 80",
+            "7k/8/5KQ1/8/8/8/8/8 w - - 0 1",              # mates and stalemates one ply away
+            "6k1/5ppp/8/8/8/8/5PPP/R5K1 w - - 0 1",        # back-rank mate available
+            "k7/2Q5/1K6/8/8/8/8/8 b - - 10 1",             # black to move, nearly stalemated
+            "r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1"]        # castling both sides in the tree
+    G, sims = len(fens), 90
+    games = [OracleGame(board=board_from_fen(f)) for f in fens]
+    net = FakeNet(seed=13, prior_shift=30)
+    eng = LockstepEngine(net.to("cuda:0"), n_games=G, max_sims=sims)
+    eng.ctx.set_positions(np.stack([board_to_array(board_from_fen(f)) for f in fens]))
+    eng.search(sims)
+    rc = eng.root_children()
+    cnt = eng.ctx.counters()
+    assert cnt["terminal_hits"] > 0
+    for i, g in enumerate(games):
+        if g.get_result() is not None:
+            assert rc["nchild"][i] == 0
+            continue
+        r = mcts_oracle.search(g, mcts_oracle.OracleAgent(net), sims, noise=False)
+        n = rc["nchild"][i]
+        assert list(rc["visits"][i, :n]) == r.visits, fens[i]
+        assert [move_to_uci(m) for m in rc["moves"][i, :n]] == r.child_moves
+        exp_rep = [0xFFFF if u == "00000" else uci_to_move(u) for u in r.child_replies]
+        assert list(rc["replies"][i, :n]) == exp_rep, fens[i]
+        assert np.array_equal(rc["values"][i, :n].view(np.uint64),
+                              np.array(r.values, dtype=np.float64).view(np.uint64)), fens[i]
+    eng.close()
+
+
 def test_search_then_advance_matches_oracle_game():
     """Three full moves of selfplay.play_game (search -> choose -> two pushes), noise off."""
     from chessrl_amd.engine import LockstepEngine, compute_policy
