@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64) void k_backup(Dev d, const float *pol2, const f
     backup_pending(d, g, r, lane, pol2, val2);
 }
 
-__global__ __launch_bounds__(64) void k_select_expand(Dev d, const float *pol2, const float *val2,
+__global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol2, const float *val2,
                                                       void *planes1)
 {
     __shared__ WaveLds s;

@@ -80,7 +80,9 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
 
 
 
-template <int DIST, int ASMRD>
+// DIAG (timing only, WRONG results): 1 = no weight staging in the loop, 2 = no per-tile barrier,
+// 3 = neither
+template <int DIST, int ASMRD, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *__restrict__ planes,
                                                            const unsigned char *__restrict__ wts,
                                                            const float *__restrict__ bias,
@@ -213,9 +215,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                     if constexpr ((i & 3) == 2) {
                         if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
+                        if (!(DIAG & 2)) __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
-                        if (t + 3 < n_tiles) stage_wtile_p2(wts, lds, t + 3, tid);
+                        // DIAG & 4 (correct results): stagger the staging -- waves 0-3 here, waves 4-7
+                        // half a K-step later -- so that the two waves of a SIMD do not issue their
+                        // LDS-DMA together.  Measured 2 % SLOWER than staging together: kept off.
+                        if (!(DIAG & 1) && t + 3 < n_tiles && (!(DIAG & 4) || wave < 4))
+                            stage_wtile_p2(wts, lds, t + 3, tid);
+                    }
+                    if constexpr ((i & 3) == 0) {
+                        // start of K-step t: tile t+2's buffer was recycled by the last mid-step barrier
+                        if (!(DIAG & 1) && (DIAG & 4) && wave >= 4 && t > 0 && t + 2 < n_tiles)
+                            stage_wtile_p2(wts, lds, t + 2, tid);
                     }
                     constexpr bool wrap = i + 1 >= 24;
                     bool issued = false;
