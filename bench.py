@@ -187,7 +187,7 @@ def main():
             # 192 F) MACs per board x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            k_name = "crl_tower::k_trunk128_pipe<1,1> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
+            k_name = "crl_tower::k_trunk128_pipe<0> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats

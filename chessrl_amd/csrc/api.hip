@@ -467,19 +467,17 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
     const int var = ev ? atoi(ev) : 0;
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
-    kern_t kern = crl_tower::k_trunk128_pipe<1, 1>;    // production: pinned pipeline, hand-counted reads
+    kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production
     int lds_bytes = crl_tower::P2_LDS_BYTES;
     switch (var) {
     case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 3: kern = crl_tower::k_trunk128<3>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = crl_tower::LDS_BYTES; break;   // unpipelined baseline
-    case 6: kern = crl_tower::k_trunk128_pipe<2, 0>; break;                                // prefetch distance 2
-    case 7: kern = crl_tower::k_trunk128_pipe<1, 0>; break;                                // compiler-counted reads
-    case 201: kern = crl_tower::k_trunk128_pipe<1, 1, 1>; break;
-    case 202: kern = crl_tower::k_trunk128_pipe<1, 1, 2>; break;
-    case 203: kern = crl_tower::k_trunk128_pipe<1, 1, 3>; break;
-    case 204: kern = crl_tower::k_trunk128_pipe<1, 1, 4>; break;   // staggered staging (correct results)
+    case 201: kern = crl_tower::k_trunk128_pipe<1>; break;
+    case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
+    case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
+    case 204: kern = crl_tower::k_trunk128_pipe<4>; break;   // staggered staging (correct results)
     case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = crl_tower::LDS_BYTES; break;

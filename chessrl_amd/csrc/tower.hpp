@@ -1,5 +1,7 @@
 // tower.hpp -- fused residual trunk of the policy/value tower for gfx950 (MFMA, fp16 in,
-// fp32 accumulate), F = 128 filters.
+// fp32 accumulate), F = 128 filters.  FIRST BUILD: the design and the shared constants live here;
+// the production kernel is the software-pipelined tower_pipe.hpp (bit-identical results).  This
+// one stays as the baseline of the tuning ladder and carries the timing-only diagnostic variants.
 //
 // Replaces the trunk of ChessModel (/root/reference/src/chessrl/model.py:33-37,111-122: stem
 // Conv3x3 + N x [Conv3x3-BN-ReLU-Conv3x3-BN-add-ReLU]) for inference.  BatchNorm is folded into
@@ -28,8 +30,8 @@
 //   * LDS images are XOR-swizzled in 16-B chunks (activations: chunk ^ (pos & 15); weight tile:
 //     chunk ^ ((row >> 1) & 7), applied on the SOURCE address of the LDS-DMA) so that every
 //     ds_read_b128 lane group covers all 64 banks.
-// The heads (1x1 convs + dense layers, < 1 % of the FLOPs) stay in PyTorch and read the fp32
-// trunk output.
+// The three 1x1 head convolutions are reduced in the kernel's tail; the dense layers (< 1 % of the
+// FLOPs) stay in PyTorch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,22 +1,33 @@
-// tower_pipe.hpp -- PRODUCTION build of the fused trunk: tower.hpp's structure, software-
-// pipelined, with an ADDRESS-FREE inner loop: the activation image is
-// padded (272-byte rows) instead of XOR-swizzled, so every activation fragment read is one
-// per-tap base register + an immediate offset, and the weight fragment offsets are computed once
-// per kernel.  tower.hpp spends ~4 VALU instructions per MFMA on fragment addresses; with two
-// waves per SIMD sharing one issue port that is what keeps the matrix pipe at ~50 %.
-// (same math and weight tile format as tower.hpp; results are bit-identical to it).
+// tower_pipe.hpp -- PRODUCTION build of the fused residual trunk (128 filters) for gfx950.
 //
-// What tower.hpp's rocprofv3 counters showed at the C3 shape (profiles/r01): MFMA pipe 51 % busy,
-// waves parked in s_waitcnt/s_barrier 38 % of their cycles, LDS array only 39 % busy -- the loss
-// is LDS *latency* at the start of every 16-channel sub-step and of every K-step, not bandwidth.
-// This build hides it:
-//   * operand fragments are fetched TWO sub-steps ahead into a rotating set of three register
-//     groups (compile-time rotation: the 24 sub-steps of three taps are fully unrolled);
-//   * the weight ring is four tiles deep and the per-tile `s_waitcnt vmcnt; s_barrier` sits in
-//     the MIDDLE of a K-step (before sub-step 2): it publishes tile t+1 two sub-steps before its
-//     first fragment read is issued, so MFMAs of tile t are still queued behind the barrier and
-//     the matrix pipe does not drain at K-step boundaries;
-//   * the only full drains left are the two barriers around each layer's epilogue.
+// Same math, weight tile format and wave tiling as tower.hpp (read its header first: LDS-resident
+// boards, fp32 residual stream in registers, LDS-DMA weight ring, transposed product, in-place
+// epilogue); results are bit-identical to it.  tower.hpp is the first, straightforward build and is
+// kept as the baseline of the ladder in profiles/r01/pmc_trunk_kernel.md.  Its rocprofv3 counters
+// at the C3 shape showed the matrix pipe 51 % busy, waves parked in s_waitcnt/s_barrier 38 % of
+// their cycles, ~4 VALU instructions per MFMA, the LDS array 39 % busy with 18 % conflicts.  What
+// this build changes, in the order it paid:
+//
+//   1. ADDRESS-FREE inner loop.  The activation image is padded (272-byte rows: 16 consecutive
+//      rows start on 16 different 4-bank groups, as the XOR swizzle did) so a fragment read is
+//      `base(tap, position tile) + immediate`; weight fragment offsets are computed once per
+//      kernel.  Non-MFMA VALU per MFMA: 3.9 -> 1.9.
+//   2. PINNED SOFTWARE PIPELINE.  Fragments of sub-step u+1 are issued before the MFMAs of
+//      sub-step u.  hipcc undoes that in two ways: its scheduler sinks the reads to their first
+//      use, and its waitcnt pass answers a pinned prefetch with `lgkmcnt(0)` right behind the
+//      newest reads.  So the order is pinned with sched_barrier(0) and the reads are inline-asm
+//      `ds_read_b128` counted by hand (`s_waitcnt lgkmcnt(4)`: the 4 newest may be in flight).
+//   3. MID-STEP BARRIER.  The weight ring is four tiles deep; the per-tile
+//      `s_waitcnt vmcnt(2); s_barrier` sits before sub-step 2 of a K-step: it publishes tile t+1
+//      two sub-steps before its first fragment read, so the matrix pipe does not drain at tile
+//      boundaries (barrier cost now 1.7 %).
+//   4. CONFLICT-FREE ZERO ROWS.  Off-board neighbours read one of 16 zero rows laid out like board
+//      rows, i.e. on the bank group the lane would have used in-board (conflicts 18 % -> 5 %).
+//
+// Remaining costs (DIAG builds): weight staging 12.5 % (5 TB/s of L2->LDS traffic chip-wide; the
+// only cure is more boards per workgroup, which LDS does not allow), epilogue + pipeline refill
+// per layer ~3 %.  Without staging the kernel runs at the rate of a bare MFMA micro-benchmark
+// with changing operands (1.5-1.6 PFLOP/s on this chip).
 #pragma once
 #include <type_traits>
 #include "tower.hpp"
@@ -35,10 +46,7 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-// ds_read_b128 the compiler does not see: hipcc's waitcnt pass answers a pinned prefetch with
-// `s_waitcnt lgkmcnt(0)` right behind the newest reads, i.e. it waits for the data of the NEXT
-// sub-step before issuing the MFMAs of the current one.  These reads are counted by hand
-// (`s_waitcnt lgkmcnt(4)` = the 4 newest may still be in flight).
+// ds_read_b128 the compiler does not see (see point 2 above)
 template <int OFF>
 __device__ __forceinline__ half8 lds_read16_asm(int addr)
 {
@@ -47,21 +55,17 @@ __device__ __forceinline__ half8 lds_read16_asm(int addr)
     return v;
 }
 
-// padded activation image: row stride 272 B = 68 dwords -> 16 rows with distinct (row mod 16)
-// start on 16 different 4-bank groups, exactly what the XOR swizzle achieved
-constexpr int P2_AROW = ROW_BYTES + 16;
+constexpr int P2_AROW = ROW_BYTES + 16;                             // padded activation row
 constexpr int P2_ABOARD = 64 * P2_AROW;
-// off-board neighbours read zeros.  A single zero row would sit on ONE bank group and collide with
-// whichever in-board lane of the same ds_read_b128 group owns it (rocprofv3: 18 % of the LDS cycles
-// were conflicts); 16 zero rows laid out like board rows let an off-board lane read the row whose
-// bank group it would have used in-board: conflict-free by construction.
-constexpr int P2_ZERO_OFF = BOARDS_PER_WG * P2_ABOARD;
-constexpr int P2_ZERO_BYTES = 16 * P2_AROW;                         // 4352 B
-constexpr int P2_BIAS_OFF = P2_ZERO_OFF + P2_ZERO_BYTES;
+constexpr int P2_ZERO_OFF = BOARDS_PER_WG * P2_ABOARD;              // 16 zero rows
+constexpr int P2_ZERO_BYTES = 16 * P2_AROW;
+constexpr int P2_BIAS_OFF = P2_ZERO_OFF + P2_ZERO_BYTES;            // float [MAX_CONVS][128]
 constexpr int P2_WRING_OFF = ((P2_BIAS_OFF + MAX_CONVS * CH * 4 + 1023) / 1024) * 1024;
 constexpr int P2_LDS_BYTES = P2_WRING_OFF + PIPE_RING * WTILE_BYTES;
 static_assert(P2_LDS_BYTES <= 160 * 1024, "LDS budget");
 
+// stage weight tile t into ring slot t & 3: LDS image linear per wave instruction, XOR swizzle
+// (chunk ^ ((row >> 1) & 7)) applied to the per-lane SOURCE address
 __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, int t, int tid)
 {
     const unsigned char *src = wts + (size_t)t * WTILE_BYTES;
@@ -78,11 +82,10 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
     }
 }
 
-
-
-// DIAG (timing only, WRONG results): 1 = no weight staging in the loop, 2 = no per-tile barrier,
-// 3 = neither
-template <int DIST, int ASMRD, int DIAG = 0>
+// DIAG = 0: production.  Timing-only builds (WRONG results): bit 0 = no weight staging in the loop,
+// bit 1 = no per-tile barrier.  Bit 2 (correct results) = staggered staging: waves 0-3 stage at the
+// mid-step barrier, waves 4-7 half a K-step later (measured 2 % slower than staging together).
+template <int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *__restrict__ planes,
                                                            const unsigned char *__restrict__ wts,
                                                            const float *__restrict__ bias,
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
+    const int lds_base = (int)(size_t)lds;              // LDS byte address of the dynamic array
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int board = wave >> 1, nh = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -105,11 +109,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
     stage_wtile_p2(wts, lds, 1, tid);
     stage_wtile_p2(wts, lds, 2, tid);
 
+    // ---- planes -> padded LDS image; zero rows; biases -------------------------------------------------
     {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int c16 = i * 512 + tid;
+            const int c16 = i * 512 + tid;              // 16-B chunk of the 64-KiB input block
             const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
             u32x4 v = src[c16];
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
@@ -121,12 +126,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         for (int i = tid; i < n_convs * CH; i += 512)
             *reinterpret_cast<__attribute__((address_space(3))) float *>(lds + P2_BIAS_OFF + i * 4) = bias[i];
     }
-    // tile 0 landed (tiles 1,2 may be in flight), planes/bias/zero row written: publish
+    // tile 0 landed (tiles 1,2 may be in flight), planes/bias/zero rows written: publish
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    int px[2], py[2];
+    int px[2], py[2];                                   // the lane's two positions p = 32*mt + r
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) { const int p = 32 * mt + r; px[mt] = p & 7; py[mt] = p >> 3; }
     int waddr[2][4];                                    // weight fragment offset inside a tile
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         for (int s = 0; s < 4; s++) waddr[nt][s] = o * 128 + (((2 * s + h) ^ ((o >> 1) & 7)) << 4);
     }
 
-    f32x16 res[2][2];
+    f32x16 res[2][2];                                   // fp32 residual stream [mt][nt]
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -155,8 +160,6 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
 
-        // fragment fetch of sub-step i (0..23) of tap block blk (3 taps = 24 sub-steps): tap
-        // 3*blk + i/8, channel half (i/4)&1, 16-channel step i&3; weight tile t_conv0 + 6*blk + i/4
         const int t_conv0 = t;
         // per-tap activation base (one VGPR per position tile): everything else is an immediate
         auto tap_base = [&](int tap, int mt) {
@@ -164,18 +167,21 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             const int yy = py[mt] + dy, xx = px[mt] + dx;
             const bool ok = ((unsigned)yy < 8u) && ((unsigned)xx < 8u);
             const int pp = yy * 8 + xx;
-            return (ok ? board * P2_ABOARD + pp * P2_AROW : P2_ZERO_OFF + (pp & 15) * P2_AROW) + h * 16;
+            return lds_base + (ok ? board * P2_ABOARD + pp * P2_AROW : P2_ZERO_OFF + (pp & 15) * P2_AROW) +
+                   h * 16;
         };
+        // sub-step i (0..23) of tap block blk (3 taps = 24 sub-steps): tap 3*blk + i/8, channel half
+        // (i/4)&1, 16-channel step i&3; weight tile t_conv0 + 6*blk + i/4
         int ab[4][2];                                   // taps of the current block + first of the next
-        auto fetch = [&](int blk, int i, bool next_blk, Frags &f) {
-            const int kc = (i >> 2) & 1, s = i & 3;
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-                f.x[mt] = lds_read16(lds, ab[next_blk ? 3 : (i >> 3)][mt] + (kc * 8 + 2 * s) * 16);
-            const lds_byte *wbuf =
-                lds + P2_WRING_OFF + ((t_conv0 + 6 * blk + (i >> 2)) & (PIPE_RING - 1)) * WTILE_BYTES;
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) f.w[nt] = lds_read16(wbuf, waddr[nt][s]);
+        auto fetch = [&](auto IC, int blk, bool next_blk, Frags &f) {
+            constexpr int i = decltype(IC)::value;
+            constexpr int kc = (i >> 2) & 1, s4 = i & 3;
+            f.x[0] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][0]);
+            f.x[1] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][1]);
+            const int wb = lds_base + P2_WRING_OFF +
+                           ((t_conv0 + 6 * blk + (i >> 2)) & (PIPE_RING - 1)) * WTILE_BYTES;
+            f.w[0] = lds_read16_asm<0>(wb + waddr[0][s4]);
+            f.w[1] = lds_read16_asm<0>(wb + waddr[1][s4]);
         };
         auto mfma4 = [&](const Frags &f) {
 #pragma unroll
@@ -185,72 +191,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[nt], f.x[mt], acc[mt][nt], 0, 0, 0);
         };
 
-        Frags f0, f1, f2;
+        Frags f0, f1;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) ab[3][mt] = tap_base(0, mt);
-        if constexpr (ASMRD) {
-            // hand-counted variant (prefetch distance 1)
-            const int lds_base = (int)(size_t)lds;      // LDS byte address of the dynamic array
-            auto fetch_asm = [&](auto IC, int blk, bool next_blk, Frags &f) {
-                constexpr int i = decltype(IC)::value;
-                constexpr int kc = (i >> 2) & 1, s4 = i & 3;
-                f.x[0] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(lds_base + ab[next_blk ? 3 : (i >> 3)][0]);
-                f.x[1] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(lds_base + ab[next_blk ? 3 : (i >> 3)][1]);
-                const int wb = lds_base + P2_WRING_OFF +
-                               ((t_conv0 + 6 * blk + (i >> 2)) & (PIPE_RING - 1)) * WTILE_BYTES;
-                f.w[0] = lds_read16_asm<0>(wb + waddr[0][s4]);
-                f.w[1] = lds_read16_asm<0>(wb + waddr[1][s4]);
-            };
-            for (int blk = 0; blk < 3; blk++) {
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++) {
-                    ab[0][mt] = ab[3][mt];
-                    ab[1][mt] = tap_base(3 * blk + 1, mt);
-                    ab[2][mt] = tap_base(3 * blk + 2, mt);
-                    ab[3][mt] = tap_base(blk < 2 ? 3 * blk + 3 : 0, mt);
-                }
-                if (blk == 0) fetch_asm(std::integral_constant<int, 0>{}, 0, false, f0);
-                static_for<0, 24>([&](auto IC) {
-                    constexpr int i = decltype(IC)::value;
-                    if constexpr ((i & 3) == 2) {
-                        if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (!(DIAG & 2)) __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        // DIAG & 4 (correct results): stagger the staging -- waves 0-3 here, waves 4-7
-                        // half a K-step later -- so that the two waves of a SIMD do not issue their
-                        // LDS-DMA together.  Measured 2 % SLOWER than staging together: kept off.
-                        if (!(DIAG & 1) && t + 3 < n_tiles && (!(DIAG & 4) || wave < 4))
-                            stage_wtile_p2(wts, lds, t + 3, tid);
-                    }
-                    if constexpr ((i & 3) == 0) {
-                        // start of K-step t: tile t+2's buffer was recycled by the last mid-step barrier
-                        if (!(DIAG & 1) && (DIAG & 4) && wave >= 4 && t > 0 && t + 2 < n_tiles)
-                            stage_wtile_p2(wts, lds, t + 2, tid);
-                    }
-                    constexpr bool wrap = i + 1 >= 24;
-                    bool issued = false;
-                    if (!wrap || blk < 2) {
-                        issued = true;
-                        if constexpr (wrap) {
-                            if constexpr (i % 2 == 0) fetch_asm(std::integral_constant<int, 0>{}, blk + 1, true, f1);
-                            else fetch_asm(std::integral_constant<int, 0>{}, blk + 1, true, f0);
-                        } else {
-                            if constexpr (i % 2 == 0) fetch_asm(std::integral_constant<int, i + 1>{}, blk, false, f1);
-                            else fetch_asm(std::integral_constant<int, i + 1>{}, blk, false, f0);
-                        }
-                    }
-                    // operands of THIS sub-step have landed; the 4 reads just issued may be in flight
-                    if (issued) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (i % 2 == 0) mfma4(f0);
-                    else mfma4(f1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr ((i & 3) == 3) t++;
-                });
-            }
-        } else {
         for (int blk = 0; blk < 3; blk++) {             // 3 blocks x 24 sub-steps (3 taps each)
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
@@ -259,50 +202,45 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                 ab[2][mt] = tap_base(3 * blk + 2, mt);
                 ab[3][mt] = tap_base(blk < 2 ? 3 * blk + 3 : 0, mt);
             }
-            if (blk == 0) {
-                fetch(0, 0, false, f0);
-                if (DIST == 2) fetch(0, 1, false, f1);
-            }
-#pragma unroll
-            for (int i = 0; i < 24; i++) {
-                if ((i & 3) == 2) {
-                    // middle of K-step t: publish tile t+1 (its first read is issued DIST sub-steps
+            if (blk == 0) fetch(std::integral_constant<int, 0>{}, 0, false, f0);
+            static_for<0, 24>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                if constexpr ((i & 3) == 2) {
+                    // middle of K-step t: publish tile t+1 (its first read is issued one sub-step
                     // before its K-step starts), recycle the buffer of tile t-1 for tile t+3
                     if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    if (!(DIAG & 2)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t + 3 < n_tiles) stage_wtile_p2(wts, lds, t + 3, tid);
+                    if (!(DIAG & 1) && t + 3 < n_tiles && (!(DIAG & 4) || wave < 4))
+                        stage_wtile_p2(wts, lds, t + 3, tid);
                 }
-                // prefetch sub-step +DIST into the register group that sub-step -1 just released
-                const bool wrap = i + DIST >= 24;
+                if constexpr ((i & 3) == 0) {
+                    if (!(DIAG & 1) && (DIAG & 4) && wave >= 4 && t > 0 && t + 2 < n_tiles)
+                        stage_wtile_p2(wts, lds, t + 2, tid);
+                }
+                // prefetch the next sub-step into the register group the previous one released
+                constexpr bool wrap = i + 1 >= 24;
+                bool issued = false;
                 if (!wrap || blk < 2) {
-                    const int pb = wrap ? blk + 1 : blk, pi = wrap ? i + DIST - 24 : i + DIST;
-                    if (DIST == 2) {
-                        if (i % 3 == 0) fetch(pb, pi, wrap, f2);
-                        else if (i % 3 == 1) fetch(pb, pi, wrap, f0);
-                        else fetch(pb, pi, wrap, f1);
+                    issued = true;
+                    if constexpr (wrap) {
+                        if constexpr (i % 2 == 0) fetch(std::integral_constant<int, 0>{}, blk + 1, true, f1);
+                        else fetch(std::integral_constant<int, 0>{}, blk + 1, true, f0);
                     } else {
-                        if (i % 2 == 0) fetch(pb, pi, wrap, f1);
-                        else fetch(pb, pi, wrap, f0);
+                        if constexpr (i % 2 == 0) fetch(std::integral_constant<int, i + 1>{}, blk, false, f1);
+                        else fetch(std::integral_constant<int, i + 1>{}, blk, false, f0);
                     }
                 }
-                // pin the software pipeline: hipcc otherwise sinks the prefetch down to its first
-                // use (lgkmcnt(0) in front of every MFMA group) to save registers
+                // operands of THIS sub-step have landed; the 4 reads just issued may be in flight
+                if (issued) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (DIST == 2) {
-                    if (i % 3 == 0) mfma4(f0);
-                    else if (i % 3 == 1) mfma4(f1);
-                    else mfma4(f2);
-                } else {
-                    if (i % 2 == 0) mfma4(f0);
-                    else mfma4(f1);
-                }
+                if constexpr (i % 2 == 0) mfma4(f0);
+                else mfma4(f1);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((i & 3) == 3) t++;
-            }
-        }
-
+                if constexpr ((i & 3) == 3) t++;
+            });
         }
 
         // ---- epilogue: every wave has finished reading the activation buffer ----------------------
@@ -310,8 +248,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const bool is_stem = conv == 0;
-        const bool is_conv2 = !is_stem && ((conv & 1) == 0);
-        const bool keep_res = !is_stem && !is_conv2;
+        const bool is_conv2 = !is_stem && ((conv & 1) == 0);     // convs 1,3,.. = conv1; 2,4,.. = conv2
+        const bool keep_res = !is_stem && !is_conv2;             // conv1 leaves the skip stream alone
         const float relu_floor = is_stem ? -__builtin_inff() : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
@@ -320,12 +258,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int o0 = 64 * nh + 32 * nt + 8 * g + 4 * h;
+                    const int o0 = 64 * nh + 32 * nt + 8 * g + 4 * h;     // 4 consecutive channels
                     const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
                         lds + P2_BIAS_OFF + (conv * CH + o0) * 4);
                     half4 o16;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
+                        // wave-uniform selects instead of branches: stem = bias only (no BN, no
+                        // activation, model.py:33-34); conv1 = ReLU; conv2 = +skip, ReLU
                         const float skip = is_conv2 ? res[mt][nt][4 * g + j] : 0.f;
                         float v = (acc[mt][nt][4 * g + j] + bv[j]) + skip;
                         v = fmaxf(v, relu_floor);
@@ -343,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // ---- optional trunk output: fp32 residual stream -> global [board][pos][ch] -----------------------
     if (out) {
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
@@ -360,6 +301,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         }
     }
 
+    // ---- head 1x1 convolutions (policy 2 ch, value 1 ch; BN folded) + ReLU, in fp32 -----------------
+    // model.py:40-42,51-55.  A position's 128 channels are spread over 2 waves x 2 lane halves: each
+    // lane reduces its 32 channels, the 4 partial sums meet in LDS (the activation buffer is dead
+    // now) and are added in a FIXED order (no float atomics: results are reproducible).
     if (head_out) {
         float part[2][3];
 #pragma unroll
@@ -390,9 +335,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int i = tid; i < BOARDS_PER_WG * 64 * 3; i += 512) {
-            const int k = i % 3, bp = i / 3;
+            const int k = i % 3, bp = i / 3;           // bp = board * 64 + position
             const f32x4 c = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(scratch + i * 4);
             const float v = (((c[0] + c[1]) + c[2]) + c[3]) + head_b[k];
+            // per board 192 floats: [0,128) = policy head in Keras Flatten order (pos*2 + ch),
+            // [128,192) = value head (pos): both dense layers read them without a gather
             const size_t gb = wg_board0 + (bp >> 6);
             const int pos = bp & 63;
             head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
