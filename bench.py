@@ -123,10 +123,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # self-test hooks (1-GPU box): CRL_BENCH_DEVICE pins every rank to one device and
+    # CRL_BENCH_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
+    if "CRL_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["CRL_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local)
@@ -239,6 +247,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()            # rank 0 is still profiling its phases: nobody tears NCCL down early
     run.close()
     if world > 1:
         dist.destroy_process_group()

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.path.join(_PKG, "libchessrl_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp", "tower.hpp", "tower_pipe.hpp")]
+           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp", "tower.hpp", "tower_pipe.hpp", "tower_gen.hpp")]
 HEADER = os.path.join(_ROOT, "include", "chessrl_hip.h")
 
 MAX_MOVES = 256
@@ -31,7 +31,7 @@ SYMBOLS = [
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
-    "crl_advance", "crl_counters", "crl_trunk128_forward",
+    "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.crl_advance.argtypes = [vp, vp, vp, vp]
     L.crl_counters.argtypes = [vp, vp]
     L.crl_trunk128_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     for name in SYMBOLS:
         if name not in ("crl_destroy", "crl_last_error"):
             getattr(L, name).restype = ctypes.c_int

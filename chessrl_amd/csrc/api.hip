@@ -4,6 +4,7 @@
 #include "search.hpp"
 #include "tower.hpp"
 #include "tower_pipe.hpp"
+#include "tower_gen.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -453,22 +454,44 @@ int crl_counters(crl_ctx *ctx, uint64_t *out6)
 }
 
 // ---- tower seam (model.py) -------------------------------------------------------------------
+int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
+                      const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                      int n_boards, int n_blocks, const void *dev_head_w_f32,
+                      const void *dev_head_b_f32, void *dev_head_out_f32);
+
 int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const void *dev_wtiles_f16,
                          const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
                          const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32)
 {
+    return crl_trunk_forward(hip_stream, 128, dev_planes_f16, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+                             n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
+}
+
+int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
+                      const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                      int n_boards, int n_blocks, const void *dev_head_w_f32,
+                      const void *dev_head_b_f32, void *dev_head_out_f32)
+{
+    if (filters != 128 && filters != 256)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 128 and 256 filters");
     if (!dev_planes_f16 || !dev_wtiles_f16 || !dev_bias_f32 || (!dev_out_f32 && !dev_head_out_f32) ||
         (dev_head_out_f32 && (!dev_head_w_f32 || !dev_head_b_f32)) || n_boards < 4 ||
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
         1 + 2 * n_blocks > crl_tower::MAX_CONVS)
-        return fail(nullptr, CRL_ERR_ARG, "crl_trunk128_forward: bad argument");
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
     // CRL_TRUNK_VARIANT selects a tuning/diagnostic build of the kernel (unset/0 = production)
     const char *ev = getenv("CRL_TRUNK_VARIANT");
     const int var = ev ? atoi(ev) : 0;
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
-    kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production
+    kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production, 128 filters
     int lds_bytes = crl_tower::P2_LDS_BYTES;
+    int boards_per_wg = crl_tower::BOARDS_PER_WG;
+    if (filters == 256) {
+        kern = crl_tower::k_trunk_gen<256>;
+        lds_bytes = crl_tower::Geo<256>::LDS_BYTES;
+        boards_per_wg = crl_tower::Geo<256>::NB;
+    } else
     switch (var) {
     case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = crl_tower::LDS_BYTES; break;
@@ -478,6 +501,7 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
     case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
     case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
     case 204: kern = crl_tower::k_trunk128_pipe<4>; break;   // staggered staging (correct results)
+    case 300: kern = crl_tower::k_trunk_gen<128>; lds_bytes = crl_tower::Geo<128>::LDS_BYTES; break;   // generic kernel at F = 128
     case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = crl_tower::LDS_BYTES; break;
     case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = crl_tower::LDS_BYTES; break;
@@ -490,7 +514,7 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
     hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         lds_bytes);
     if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
-    hipLaunchKernelGGL(kern, dim3(n_boards / crl_tower::BOARDS_PER_WG), dim3(512),
+    hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),
                        lds_bytes, (hipStream_t)hip_stream,
                        (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,
                        (const float *)dev_bias_f32, (float *)dev_out_f32, n_blocks,

@@ -179,15 +179,18 @@ class ChessModel(object):
         net.load_keras_dict(weights)
         self.net = net.cast_for_inference(self.device, self.dtype)
         self.blocks, self.filters = blocks, filters
-        # the hand-written fused MFMA trunk (csrc/tower.hpp) covers 128 filters in fp16
-        self.fused = bool(self.want_fused and filters == 128 and self.dtype == torch.float16
+        # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 128 and 256
+        # filters in fp16
+        self.fused = bool(self.want_fused and filters in (128, 256) and self.dtype == torch.float16
                           and 1 + 2 * blocks <= 41)
         if self.fused:
             self._pack_fused(weights)
 
     def _pack_fused(self, w):
         """BN-folded fp16 kernels as 16-KiB tiles in the kernel's consumption order
-        [conv][tap=ky*3+kx][in-ch/64][128 out][64 in]; biases f32 [conv][128]."""
+        [conv][tap=ky*3+kx][in-ch/KT][F out][KT in] with KT = 64 (F = 128) or 32 (F = 256);
+        biases f32 [conv][F]."""
+        F_, kt = self.filters, (64 if self.filters == 128 else 32)
         names = [("stem", None)]
         for i in range(self.blocks):
             names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
@@ -198,19 +201,20 @@ class ChessModel(object):
                 kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
                 kp[:, :k.shape[1]] = k
                 k = kp
-            t = k.permute(2, 3, 0, 1).reshape(9, 128, 2, 64).permute(0, 2, 1, 3)   # [tap][kc][o][c]
-            tiles.append(t.contiguous())
+            cin = k.shape[1]                                   # 128 for the stem, F otherwise
+            t = k.permute(2, 3, 0, 1).reshape(9, F_, cin // kt, kt).permute(0, 2, 1, 3)   # [tap][kc][o][c]
+            tiles.append(t.contiguous().reshape(-1))
             biases.append(b)
-        self._wtiles = torch.stack(tiles).to(self.device, torch.float16).contiguous()
+        self._wtiles = torch.cat(tiles).to(self.device, torch.float16).contiguous()
         self._wbias = torch.stack(biases).to(self.device, torch.float32).contiguous()
         kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][128][1][1]
         kv, bv = _fold(w, "value.conv", "value.bn")            # [1][128][1][1]
-        self._head_w = torch.cat([kp.reshape(2, 128), kv.reshape(1, 128)]).to(self.device).contiguous()
+        self._head_w = torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).to(self.device).contiguous()
         self._head_b = torch.cat([bp, bv]).to(self.device).contiguous()
         self._pad_in = None
 
     def _run_fused(self, planes, want_trunk=False):
-        """One launch of the fused trunk kernel.  Returns (trunk fp32 [B,8,8,128] or None,
+        """One launch of the fused trunk kernel.  Returns (trunk fp32 [B,8,8,F] or None,
         head activations fp32 [B,192] = ReLU(1x1 head convs): 128 policy + 64 value)."""
         import ctypes
         from . import _lib
@@ -221,17 +225,18 @@ class ChessModel(object):
                 self._pad_in = torch.zeros((bp, 8, 8, PAD_PLANES), dtype=torch.float16, device=self.device)
             self._pad_in[:b].copy_(planes)
             planes = self._pad_in
-        trunk = torch.empty((bp, 8, 8, 128), dtype=torch.float32, device=self.device) if want_trunk else None
+        trunk = (torch.empty((bp, 8, 8, self.filters), dtype=torch.float32, device=self.device)
+                 if want_trunk else None)
         heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
-        rc = _lib.lib().crl_trunk128_forward(
-            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+        rc = _lib.lib().crl_trunk_forward(
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters,
             ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(self._wtiles.data_ptr()),
             ctypes.c_void_p(self._wbias.data_ptr()),
             ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
             ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
             ctypes.c_void_p(heads.data_ptr()))
         if rc != 0:
-            raise _lib.HipLibraryError("crl_trunk128_forward failed (%d)" % rc)
+            raise _lib.HipLibraryError("crl_trunk_forward failed (%d)" % rc)
         return (trunk[:b] if want_trunk else None), heads[:b]
 
     def _forward_fused(self, planes, pol_out=None, val_out=None):

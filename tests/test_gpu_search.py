@@ -225,7 +225,7 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, rbn, dtype):
     from chessrl_amd.model import ChessModel
     w = tower_oracle.init_weights(blocks, filters, seed=4, randomize_bn=rbn)
     model = ChessModel(weights=w, dtype=getattr(torch, dtype))
-    assert model.fused == (filters == 128 and dtype == "float16")
+    assert model.fused == (filters in (128, 256) and dtype == "float16")
     vtol = 1e-3 if dtype == "float32" else FP16_VALUE_TOL[(blocks, filters, rbn)]
     ptol = 1e-3 if dtype == "float32" else FP16_POLICY_TOL.get((blocks, filters, rbn), 1e-3)
     games = random_prefix_games(30, 80, seed=9)                 # 30: not a multiple of 4 (padding path)
@@ -252,10 +252,11 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, rbn, dtype):
     eng.close()
 
 
-def test_fused_trunk_matches_pytorch_trunk_activations():
+@pytest.mark.parametrize("filters", [128, 256])
+def test_fused_trunk_matches_pytorch_trunk_activations(filters):
     """The fused HIP trunk's fp32 activations vs the fp32 oracle trunk, element by element."""
     from chessrl_amd.model import ChessModel
-    w = tower_oracle.init_weights(3, 128, seed=11, randomize_bn=True)
+    w = tower_oracle.init_weights(3, filters, seed=11, randomize_bn=True)
     model = ChessModel(weights=w)
     ref = ChessModel(weights=w, dtype=torch.float32, fused=False)
     rng = np.random.default_rng(3)
