@@ -195,7 +195,8 @@ def main():
             # 192 F) MACs per board x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            k_name = "crl_tower::k_trunk128_pipe<0> (fused stem + %d residual blocks + head convs, %d boards)" % (B, G)
+            k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (
+                "k_trunk128_pipe<0>" if F == 128 else "k_trunk_gen<%d>" % F, B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats
@@ -210,7 +211,8 @@ def main():
         roof = {"bound": "mfma", "kernel": k_name,
                 "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
                 "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic,
-                "algorithmic_bytes": (G * 64 * 128 * 2 + (1 + 2 * B) * 9 * F * F * 2 + G * 192 * 4) if model.fused else None,
+                "algorithmic_bytes": (G * 64 * 128 * 2 + 9 * 128 * F * 2 + 2 * B * 9 * F * F * 2 + G * 192 * 4)
+                if model.fused else None,
                 "launch_ms": k_ms, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}

@@ -210,11 +210,12 @@ FP16_VALUE_TOL = {
     (6, 64, False): 2e-3, (6, 64, True): 1e-3,          # 1.0e-3 / 3e-5         (PyTorch fp16 convs)
     (10, 128, False): 1e-3, (10, 128, True): 3e-3,      # 6.1e-4 / 1.8e-3       (fused HIP trunk)
     (20, 128, False): 4e-3, (20, 128, True): 1e-2,      # 2.3e-3 / 6.8e-3       (fused HIP trunk)
-    (20, 256, False): 1e-2, (20, 256, True): 2e-2,      # 9e-4..5e-3 / 3e-3..2e-2 (PyTorch fp16 convs)
+    (20, 256, False): 1e-3, (20, 256, True): 5e-3,      # 4.0e-4 / 2.1e-3       (fused HIP trunk;
+                                                        #  PyTorch fp16 convs: 9e-4..5e-3 / 1.4e-2)
 }
-# policy: 1e-3 everywhere except 20 blocks with randomised BN, whose activations grow ~60x and make
-# the softmax peaked (max policy 0.3): measured 2.8e-3 (fused) / 9e-3 (PyTorch fp16)
-FP16_POLICY_TOL = {(20, 128, True): 5e-3, (20, 256, True): 2e-2}
+# policy: 1e-3 everywhere except 20x128 with randomised BN, whose activations grow ~60x and make
+# the softmax peaked (max policy 0.3): measured 2.8e-3
+FP16_POLICY_TOL = {(20, 128, True): 5e-3}
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
