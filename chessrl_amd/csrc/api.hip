@@ -479,9 +479,6 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
         1 + 2 * n_blocks > crl_tower::MAX_CONVS)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
-    // CRL_TRUNK_VARIANT selects a tuning/diagnostic build of the kernel (unset/0 = production)
-    const char *ev = getenv("CRL_TRUNK_VARIANT");
-    const int var = ev ? atoi(ev) : 0;
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
     kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production, 128 filters
@@ -491,29 +488,40 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         kern = crl_tower::k_trunk_gen<256>;
         lds_bytes = crl_tower::Geo<256>::LDS_BYTES;
         boards_per_wg = crl_tower::Geo<256>::NB;
-    } else
-    switch (var) {
-    case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 3: kern = crl_tower::k_trunk128<3>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = crl_tower::LDS_BYTES; break;   // unpipelined baseline
-    case 201: kern = crl_tower::k_trunk128_pipe<1>; break;
-    case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
-    case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
-    case 204: kern = crl_tower::k_trunk128_pipe<4>; break;   // staggered staging (correct results)
-    case 300: kern = crl_tower::k_trunk_gen<128>; lds_bytes = crl_tower::Geo<128>::LDS_BYTES; break;   // generic kernel at F = 128
-    case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 103: kern = crl_tower::k_trunk128<103>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 104: kern = crl_tower::k_trunk128<104>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 105: kern = crl_tower::k_trunk128<105>; lds_bytes = crl_tower::LDS_BYTES; break;
-    case 106: kern = crl_tower::k_trunk128<106>; lds_bytes = crl_tower::LDS_BYTES; break;
-    default: break;
+    } else if (const char *ev = getenv("CRL_TRUNK_VARIANT")) {
+        // tuning / timing-only builds of the 128-filter kernel (tools/trunk_bench.py; the ladder in
+        // profiles/r01/pmc_trunk_kernel.md).  Unset or 0 = production.
+        const int first = crl_tower::LDS_BYTES;        // LDS size of the first-build kernels
+        switch (atoi(ev)) {
+        case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = first; break;    // unpipelined baseline
+        case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = first; break;     // + s_setprio
+        case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = first; break;     // all reads up front
+        case 3: kern = crl_tower::k_trunk128<3>; lds_bytes = first; break;     // x reads before barrier
+        case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = first; break; // 100..106 timing only
+        case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = first; break;
+        case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = first; break;
+        case 103: kern = crl_tower::k_trunk128<103>; lds_bytes = first; break;
+        case 104: kern = crl_tower::k_trunk128<104>; lds_bytes = first; break;
+        case 105: kern = crl_tower::k_trunk128<105>; lds_bytes = first; break;
+        case 106: kern = crl_tower::k_trunk128<106>; lds_bytes = first; break;
+        case 201: kern = crl_tower::k_trunk128_pipe<1>; break;                 // 201..203 timing only
+        case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
+        case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
+        case 204: kern = crl_tower::k_trunk128_pipe<4>; break;                 // staggered staging
+        case 300: kern = crl_tower::k_trunk_gen<128>; lds_bytes = crl_tower::Geo<128>::LDS_BYTES; break;
+        default: break;
+        }
     }
-    hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        lds_bytes);
-    if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+    // opt in to > 64 KiB of dynamic LDS once per kernel
+    static std::vector<const void *> lds_ready;
+    bool seen = false;
+    for (const void *k : lds_ready) seen = seen || k == (const void *)kern;
+    if (!seen) {
+        hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            lds_bytes);
+        if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+        lds_ready.push_back((const void *)kern);
+    }
     hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),
                        lds_bytes, (hipStream_t)hip_stream,
                        (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,

@@ -164,3 +164,44 @@ def test_fifty_move_claim_and_insufficient_material(ctx):
         assert ctx.push_moves(push)[0] == 1 and games[0].move(u)
         assert ctx.results()[0] == _res(games[0])
     assert ctx.results()[0] == 0
+
+
+PERFT_KNOWN = {   # https://www.chessprogramming.org/Perft_Results -- public known answers
+    "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1": [20, 400, 8902, 197281],
+    PERFT_FENS["kiwipete"]: [48, 2039, 97862],
+    PERFT_FENS["pos3"]: [14, 191, 2812, 43238],
+    PERFT_FENS["pos4"]: [6, 264, 9467],
+    PERFT_FENS["pos5"]: [44, 1486, 62379],
+    PERFT_FENS["pos6"]: [46, 2079, 89890],
+}
+
+
+@pytest.mark.parametrize("fen", sorted(PERFT_KNOWN))
+def test_perft_known_answers_through_the_cabi(ctx, fen):
+    """perft computed ENTIRELY by the HIP kernels (legal-move counts and pushes, breadth first,
+    256 positions per launch) against the public known answers: pins the GPU legal-move SET
+    independently of the CPU oracle."""
+    G = ctx.G
+    frontier = board_to_array(board_from_fen(fen))[None]
+    got = []
+    for depth, want in enumerate(PERFT_KNOWN[fen]):
+        total, children = 0, []
+        for lo in range(0, len(frontier), G):
+            chunk = frontier[lo:lo + G]
+            ctx.set_positions(chunk)
+            moves, counts = ctx.legal_moves()
+            total += int(counts[:len(chunk)].sum())
+            if depth + 1 < len(PERFT_KNOWN[fen]):
+                pairs = [(i, moves[i, j]) for i in range(len(chunk)) for j in range(counts[i])]
+                for plo in range(0, len(pairs), G):
+                    part = pairs[plo:plo + G]
+                    ctx.set_positions(np.stack([chunk[i] for i, _ in part]))
+                    push = np.full(G, 0xFFFF, dtype=np.uint16)
+                    push[:len(part)] = [m for _, m in part]
+                    ok = ctx.push_moves(push)
+                    assert ok[:len(part)].all()
+                    children.append(ctx.get_positions(len(part)))
+        got.append(total)
+        assert total == want, (fen, depth + 1, got)
+        if children:
+            frontier = np.concatenate(children)
