@@ -233,9 +233,12 @@ def main():
             "unit": "simulations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": max_dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "C3: %d self-play games in lockstep per GPU, %d sims/move, "
+            "config": {"workload": "%s: %d self-play games in lockstep per GPU, %d sims/move, "
                                    "%d-block/%d-filter random-init tower, standard start position, "
-                                   "Dirichlet noise on" % (G, a.sims, B, F),
+                                   "Dirichlet noise on" % (
+                                       {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
+                                        (4096, 800, 20, 256): "C5 per-GPU shard"}.get(
+                                           (G, a.sims, B, F), "custom"), G, a.sims, B, F),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused), "parallelism": "games sharded, no collective on the hot path"},
             "moves_per_sec": total_sims / max_dt / a.sims,

@@ -472,8 +472,8 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
                       int n_boards, int n_blocks, const void *dev_head_w_f32,
                       const void *dev_head_b_f32, void *dev_head_out_f32)
 {
-    if (filters != 128 && filters != 256)
-        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 128 and 256 filters");
+    if (filters != 64 && filters != 128 && filters != 256)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 64, 128 and 256 filters");
     if (!dev_planes_f16 || !dev_wtiles_f16 || !dev_bias_f32 || (!dev_out_f32 && !dev_head_out_f32) ||
         (dev_head_out_f32 && (!dev_head_w_f32 || !dev_head_b_f32)) || n_boards < 4 ||
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
@@ -488,6 +488,10 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         kern = crl_tower::k_trunk_gen<256>;
         lds_bytes = crl_tower::Geo<256>::LDS_BYTES;
         boards_per_wg = crl_tower::Geo<256>::NB;
+    } else if (filters == 64) {
+        kern = crl_tower::k_trunk_gen<64>;
+        lds_bytes = crl_tower::Geo<64>::LDS_BYTES;
+        boards_per_wg = crl_tower::Geo<64>::NB;
     } else if (const char *ev = getenv("CRL_TRUNK_VARIANT")) {
         // tuning / timing-only builds of the 128-filter kernel (tools/trunk_bench.py; the ladder in
         // profiles/r01/pmc_trunk_kernel.md).  Unset or 0 = production.

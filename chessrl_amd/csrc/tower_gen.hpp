@@ -1,15 +1,17 @@
 // tower_gen.hpp -- the production trunk structure of tower_pipe.hpp (LDS-resident boards, fp32
 // residual stream in registers, 4-deep LDS-DMA weight ring, pinned hand-counted software pipeline,
 // padded activation rows, conflict-free zero rows, head convs in the tail) templated on the number
-// of filters F in {128, 256}.  F = 128 is served by the hand-tuned tower_pipe.hpp; this file is what
-// runs BASELINE config C5 (20 blocks x 256 filters).
+// of filters F in {64, 128, 256}: every tower size of BASELINE.json (C2 6x64, C3/C4 10x128, C5
+// 20x256) runs on a hand-written kernel.  F = 128 is normally served by the hand-tuned
+// tower_pipe.hpp (3.5 % faster than this template at F = 128).
 //
-// Geometry per workgroup (512 threads, 8 waves, 2 per SIMD), wave tile always 64 pos x 64 ch:
-//   F    boards/WG  waves per board  activation row   weight tile [F out][KT in]   sub-steps/tile
-//   128      4            2            272 B           128 x 64  (16 KiB)              4
-//   256      2            4            528 B           256 x 32  (16 KiB)              2
-// The stem reads the 128 input planes (channels 0..127 of the row), every other layer F channels.
-// Biases are staged per layer (F floats) instead of all layers at once: 256 filters leave no room.
+// Geometry per workgroup (512 threads, 8 waves, 2 per SIMD):
+//   F    boards  waves/board     wave tile      act. row   weight tile [F out][KT in]  sub-steps/tile
+//   64     4     2 (pos halves)  32 pos x 64 ch   272 B     64 x 64   ( 8 KiB)             4
+//   128    4     2 (ch halves)   64 pos x 64 ch   272 B    128 x 64   (16 KiB)             4
+//   256    2     4 (ch quarters) 64 pos x 64 ch   528 B    256 x 32   (16 KiB)             2
+// The stem reads the 128 input planes (channels 0..127 of the row; rows are at least 128 channels
+// wide), every other layer F channels.  Biases are staged per layer (F floats).
 #pragma once
 #include "tower_pipe.hpp"
 
@@ -17,36 +19,47 @@ namespace crl_tower {
 
 template <int F>
 struct Geo {
-    static_assert(F == 128 || F == 256, "supported filter counts");
-    static constexpr int NQ = F / 64;                   // 64-channel groups (waves per board)
-    static constexpr int NB = 8 / NQ;                   // boards per workgroup
-    static constexpr int KT = F == 128 ? 64 : 32;       // input channels per weight tile
+    static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
+    static constexpr int NQ = F / 64;                   // 64-channel groups
+    static constexpr int PH = F == 64 ? 2 : 1;          // position halves (waves splitting a board)
+    static constexpr int MT = 2 / PH;                   // 32-position tiles per wave
+    static constexpr int NB = 8 / (NQ * PH);            // boards per workgroup
+    static constexpr int KT = F == 256 ? 32 : 64;       // input channels per weight tile
     static constexpr int SPT = KT / 16;                 // 16-channel sub-steps per tile
     static constexpr int WROW = KT * 2;                 // bytes per weight-tile row
     static constexpr int WCH = WROW / 16;               // 16-B chunks per weight-tile row
-    static constexpr int AROW = F * 2 + 16;
+    static constexpr int TILE_BYTES = F * WROW;         // 8 KiB (F = 64) or 16 KiB
+    static constexpr int GL = TILE_BYTES / 8192;        // global_load_lds per thread per tile
+    static constexpr int AROW = (F < 128 ? 128 : F) * 2 + 16;
     static constexpr int ABOARD = 64 * AROW;
     static constexpr int ZERO_OFF = NB * ABOARD;
     static constexpr int ZERO_BYTES = 16 * AROW;
     static constexpr int BIAS_OFF = ZERO_OFF + ZERO_BYTES;          // float [F], current layer
     static constexpr int WRING_OFF = ((BIAS_OFF + F * 4 + 1023) / 1024) * 1024;
-    static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * WTILE_BYTES;
-    static_assert(F * KT * 2 == WTILE_BYTES, "every tile is 16 KiB");
+    static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     // swizzle of a weight-tile row: XOR of the chunk index with row bits that differ inside a
     // ds_read_b128 lane group, so 16 lanes cover all 64 banks
-    __device__ static int wswz(int row) { return F == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+    __device__ static int wswz(int row) { return WCH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+}
 
 template <int F>
 __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, int t, int tid)
 {
     typedef Geo<F> G;
-    const unsigned char *src = wts + (size_t)t * WTILE_BYTES;
-    lds_byte *dst = lds + G::WRING_OFF + (t & (PIPE_RING - 1)) * WTILE_BYTES;
+    const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
+    lds_byte *dst = lds + G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
     const int wave_base = tid & ~63;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < G::GL; j++) {
         const int idx = j * 512 + tid;                  // 16-B slot of the tile image
         const int row = idx / G::WCH, phys = idx % G::WCH;
         const int chunk = phys ^ G::wswz(row);
@@ -57,7 +70,7 @@ __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, 
 }
 
 //   planes  fp16 [n_boards][64][128]
-//   wts     fp16 16-KiB tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
+//   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
 template <int F>
@@ -70,11 +83,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                                                        float *__restrict__ head_out)
 {
     typedef Geo<F> G;
+    constexpr int MT = G::MT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
     const int lds_base = (int)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int board = wave / G::NQ, nq = wave % G::NQ;
+    const int board = wave / (G::NQ * G::PH);
+    const int nq = (wave / G::PH) % G::NQ;              // 64-channel group of this wave
+    const int pbase = 32 * (wave % G::PH);              // first position of this wave (F = 64 only)
     const int r = lane & 31, h = lane >> 5;
     const int n_convs = 1 + 2 * n_blocks;
     const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
@@ -99,13 +115,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =
                 u32x4{0u, 0u, 0u, 0u};
     }
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<2 * G::GL>();                            // tile 0 landed (tiles 1,2 may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    int px[2], py[2];
+    int px[MT], py[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) { const int p = 32 * mt + r; px[mt] = p & 7; py[mt] = p >> 3; }
+    for (int mt = 0; mt < MT; mt++) { const int p = pbase + 32 * mt + r; px[mt] = p & 7; py[mt] = p >> 3; }
     int waddr[2][G::SPT];                               // weight fragment offset inside a tile
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
@@ -114,9 +131,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
         for (int s = 0; s < G::SPT; s++) waddr[nt][s] = o * G::WROW + (((2 * s + h) ^ G::wswz(o)) << 4);
     }
 
-    f32x16 res[2][2];
+    f32x16 res[MT][2];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -124,9 +141,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
 
     int t = 0;                                          // tile of the K-step being computed
     for (int conv = 0; conv < n_convs; conv++) {
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int a = 0; a < MT; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -142,15 +159,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
             return lds_base + (ok ? board * G::ABOARD + pp * G::AROW : G::ZERO_OFF + (pp & 15) * G::AROW) +
                    h * 16;
         };
-        auto mfma4 = [&](const Frags &f) {
+        auto mfma_all = [&](const Frags &f) {
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[nt], f.x[mt], acc[mt][nt], 0, 0, 0);
         };
         Frags f0, f1;
-        int ab[2][2];                                   // [current tap, next tap][mt]
+        int ab[2][MT];                                  // [current tap, next tap][mt]
 
         // one tap = NS sub-steps of 16 input channels (NS = Cin/16); sub-step i reads channel
         // block i of the activation rows and sub-step i % SPT of weight tile t_tap0 + i / SPT
@@ -160,9 +177,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
             auto fetch = [&](auto IC, bool next_tap, Frags &f) {
                 constexpr int i = decltype(IC)::value;
                 const int tile = next_tap ? t_tap0 + NS / G::SPT : t_tap0 + i / G::SPT;
-                f.x[0] = lds_read16_asm<i * 32>(ab[next_tap ? 1 : 0][0]);
-                f.x[1] = lds_read16_asm<i * 32>(ab[next_tap ? 1 : 0][1]);
-                const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * WTILE_BYTES;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) f.x[mt] = lds_read16_asm<i * 32>(ab[next_tap ? 1 : 0][mt]);
+                const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * G::TILE_BYTES;
                 f.w[0] = lds_read16_asm<0>(wb + waddr[0][i % G::SPT]);
                 f.w[1] = lds_read16_asm<0>(wb + waddr[1][i % G::SPT]);
             };
@@ -173,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                 if constexpr (s == G::SPT - 1 - (G::SPT > 2 ? 1 : 0)) {
                     // publish tile t+1 before the sub-step that prefetches its first fragments
                     // (SPT = 4: before sub-step 2; SPT = 2: before sub-step 1); recycle tile t-1's slot
-                    if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
+                    else wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     if (t + 3 < n_tiles) stage_wtile_gen<F>(wts, lds, t + 3, tid);
@@ -191,21 +208,23 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                         else fetch(std::integral_constant<int, i + 1>{}, false, f0);
                     }
                 }
-                if (issued) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // operands of THIS sub-step have landed; the MT+2 reads just issued may be in flight
+                if (!issued) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (i % 2 == 0) mfma4(f0);
-                else mfma4(f1);
+                if constexpr (i % 2 == 0) mfma_all(f0);
+                else mfma_all(f1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s == G::SPT - 1) t++;
             });
         };
 
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) ab[1][mt] = tap_base(0, mt);
+        for (int mt = 0; mt < MT; mt++) ab[1][mt] = tap_base(0, mt);
         for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
+            for (int mt = 0; mt < MT; mt++) {
                 ab[0][mt] = ab[1][mt];
                 ab[1][mt] = tap_base(tap < 8 ? tap + 1 : 0, mt);
             }
@@ -224,8 +243,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
         const bool keep_res = !is_stem && !is_conv2;
         const float relu_floor = is_stem ? -__builtin_inff() : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            const int p = 32 * mt + r;
+        for (int mt = 0; mt < MT; mt++) {
+            const int p = pbase + 32 * mt + r;
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
 #pragma unroll
@@ -254,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
 
     if (out) {
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            const int p = 32 * mt + r;
+        for (int mt = 0; mt < MT; mt++) {
+            const int p = pbase + 32 * mt + r;
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -272,9 +291,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
     if (head_out) {
         // a position's F channels live in NQ waves x 2 lane halves: 2*NQ partial sums per output
         constexpr int NC = 2 * G::NQ;
-        float part[2][3];
+        float part[MT][3];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int k = 0; k < 3; k++) part[mt][k] = 0.f;
 #pragma unroll
@@ -286,18 +305,17 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                 for (int k = 0; k < 3; k++) {
                     const f32x4 wv = *reinterpret_cast<const f32x4 *>(head_w + k * F + o0);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        part[0][k] += res[0][nt][4 * g + j] * wv[j];
-                        part[1][k] += res[1][nt][4 * g + j] * wv[j];
-                    }
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) part[mt][k] += res[mt][nt][4 * g + j] * wv[j];
                 }
             }
         __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                scratch[(((board * 64 + 32 * mt + r) * 3) + k) * NC + nq * 2 + h] = part[mt][k];
+                scratch[(((board * 64 + pbase + 32 * mt + r) * 3) + k) * NC + nq * 2 + h] = part[mt][k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int i = tid; i < G::NB * 64 * 3; i += 512) {

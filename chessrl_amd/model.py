@@ -179,25 +179,25 @@ class ChessModel(object):
         net.load_keras_dict(weights)
         self.net = net.cast_for_inference(self.device, self.dtype)
         self.blocks, self.filters = blocks, filters
-        # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 128 and 256
-        # filters in fp16
-        self.fused = bool(self.want_fused and filters in (128, 256) and self.dtype == torch.float16
+        # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 64, 128 and
+        # 256 filters in fp16
+        self.fused = bool(self.want_fused and filters in (64, 128, 256) and self.dtype == torch.float16
                           and 1 + 2 * blocks <= 41)
         if self.fused:
             self._pack_fused(weights)
 
     def _pack_fused(self, w):
-        """BN-folded fp16 kernels as 16-KiB tiles in the kernel's consumption order
-        [conv][tap=ky*3+kx][in-ch/KT][F out][KT in] with KT = 64 (F = 128) or 32 (F = 256);
+        """BN-folded fp16 kernels as tiles in the kernel's consumption order
+        [conv][tap=ky*3+kx][in-ch/KT][F out][KT in] with KT = 64 (F = 64, 128) or 32 (F = 256);
         biases f32 [conv][F]."""
-        F_, kt = self.filters, (64 if self.filters == 128 else 32)
+        F_, kt = self.filters, (32 if self.filters == 256 else 64)
         names = [("stem", None)]
         for i in range(self.blocks):
             names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
         tiles, biases = [], []
         for conv, bn in names:
             k, b = _fold(w, conv, bn)                          # OIHW fp32
-            if k.shape[1] < PAD_PLANES:
+            if conv == "stem" and k.shape[1] < PAD_PLANES:    # 127 planes -> 128 channels
                 kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
                 kp[:, :k.shape[1]] = k
                 k = kp
