@@ -25,7 +25,7 @@ class Agent(Player):
         super().__init__(color)
         if model is None:
             from .model import ChessModel
-            model = ChessModel(weights=weights, blocks=blocks, filters=filters)
+            model = ChessModel(compile_model=True, weights=weights, blocks=blocks, filters=filters)
         self.model = model
         self.move_encodings = netencoder.get_uci_labels()
         self.uci_dict = {u: i for i, u in enumerate(self.move_encodings)}
@@ -87,8 +87,26 @@ class Agent(Player):
     def disconnect(self):
         pass
 
-    def train(self, *a, **k):
-        raise NotImplementedError("training (agent.py:64-89) is out of scope of this path")
+    def train(self, dataset, epochs=1, logdir=None, batch_size=1, validation_split=0):
+        """agent.py:64-89: train the model on recorded games."""
+        from .dataset import DatasetGame
+        from . import netencoder
+        if len(dataset) <= 0:
+            return None
+        if validation_split > 0:
+            split_point = len(dataset) - int(validation_split * len(dataset))
+            games_train = DatasetGame(dataset[:split_point])
+            val_gen = netencoder.DataGameSequence(DatasetGame(dataset[split_point:]), batch_size=batch_size)
+        else:
+            games_train, val_gen = dataset, None
+        train_gen = netencoder.DataGameSequence(games_train, batch_size=batch_size, random_flips=.1)
+        return self.model.train_generator(train_gen, epochs=epochs, logdir=logdir, val_gen=val_gen)
+
+    def save(self, path):
+        self.model.save_weights(path)
+
+    def load(self, path):
+        self.model.load_weights(path)
 
 
 AgentDistributed = Agent

@@ -3,8 +3,9 @@
 Host-side mirror of the reference's ``ChessModel``
 (/root/reference/src/chessrl/model.py:15-81): same topology and Keras inference
 semantics, parametrised by (blocks, filters) for the
-BASELINE configs; the reference's own values are (10, 256).  Forward only --
-training (model.py:69-72,83-99) is out of scope of this path.
+BASELINE configs; the reference's own values are (10, 256).  Inference is the hot
+path (fused HIP trunk); training (model.py:69-72,83-99)
+lives in chessrl_amd/train.py and hands its weights back through ``load_dict``.
 
 MI355X design notes: the input is the encoder kernel's fp16 NHWC [B,8,8,128]
 buffer used in place (channel 127 is a zero pad, so K = 9*128 is a multiple of
@@ -149,7 +150,7 @@ class Tower(nn.Module):
 
 
 class ChessModel(object):
-    """Mirror of the reference ``ChessModel`` (model.py:15-81), forward only.
+    """Mirror of the reference ``ChessModel`` (model.py:15-99).
 
     ``predict(inp)`` takes (B,8,8,127) like Keras ``model.predict`` and returns
     ``[policy (B,1968), value (B,1)]`` numpy arrays.  ``__call__(planes)`` is the
@@ -159,8 +160,8 @@ class ChessModel(object):
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
                  dtype=torch.float16, seed=0, fused=True):
-        if compile_model:
-            raise NotImplementedError("training is out of scope of the self-play simulation path")
+        self.compiled = bool(compile_model)      # model.py:69-72: Adam(lr=0.002), cce + mse
+        self._trainer = None
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
@@ -173,12 +174,20 @@ class ChessModel(object):
         self.load_dict(weights)
 
     def load_dict(self, weights):
-        self.weights = weights
+        """(Re)load a Keras-layout weight dict.  With an unchanged (blocks, filters) every device
+        tensor is overwritten IN PLACE, so hipGraphs captured over this model (LockstepEngine) stay
+        valid and see the new weights at their next replay."""
         blocks, filters = int(weights["meta.blocks"]), int(weights["meta.filters"])
-        net = Tower(blocks, filters)
-        net.load_keras_dict(weights)
-        self.net = net.cast_for_inference(self.device, self.dtype)
-        self.blocks, self.filters = blocks, filters
+        same = getattr(self, "net", None) is not None and (blocks, filters) == (self.blocks, self.filters)
+        self.weights = weights
+        if same:
+            self.net.load_keras_dict(weights)
+        else:
+            net = Tower(blocks, filters)
+            net.load_keras_dict(weights)
+            self.net = net.cast_for_inference(self.device, self.dtype)
+            self.blocks, self.filters = blocks, filters
+            self._wtiles = None
         # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 64, 128 and
         # 256 filters in fp16
         self.fused = bool(self.want_fused and filters in (64, 128, 256) and self.dtype == torch.float16
@@ -205,13 +214,17 @@ class ChessModel(object):
             t = k.permute(2, 3, 0, 1).reshape(9, F_, cin // kt, kt).permute(0, 2, 1, 3)   # [tap][kc][o][c]
             tiles.append(t.contiguous().reshape(-1))
             biases.append(b)
-        self._wtiles = torch.cat(tiles).to(self.device, torch.float16).contiguous()
-        self._wbias = torch.stack(biases).to(self.device, torch.float32).contiguous()
-        kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][128][1][1]
-        kv, bv = _fold(w, "value.conv", "value.bn")            # [1][128][1][1]
-        self._head_w = torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).to(self.device).contiguous()
-        self._head_b = torch.cat([bp, bv]).to(self.device).contiguous()
-        self._pad_in = None
+        kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][F][1][1]
+        kv, bv = _fold(w, "value.conv", "value.bn")            # [1][F][1][1]
+        new = (torch.cat(tiles).to(torch.float16), torch.stack(biases).float(),
+               torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).float(), torch.cat([bp, bv]).float())
+        if getattr(self, "_wtiles", None) is None:
+            self._wtiles, self._wbias, self._head_w, self._head_b = (
+                t.to(self.device).contiguous() for t in new)
+            self._pad_in = None
+        else:                                                  # in place: captured graphs stay valid
+            for dst, src in zip((self._wtiles, self._wbias, self._head_w, self._head_b), new):
+                dst.copy_(src)
 
     def _run_fused(self, planes, want_trunk=False):
         """One launch of the fused trunk kernel.  Returns (trunk fp32 [B,8,8,F] or None,
@@ -265,6 +278,31 @@ class ChessModel(object):
 
     def load_weights(self, weights_path):
         self.load_dict(dict(np.load(weights_path)))
+        self._trainer = None                     # optimizer state belongs to the old weights
+
+    def train_generator(self, generator, epochs=1, logdir=None, val_gen=None, verbose=0):
+        """model.py:83-99 (``fit_generator`` over a ``DataGameSequence``).  Where the reference
+        attaches a TensorBoard callback, ``logdir`` receives one JSON line per epoch in
+        ``train_log.jsonl``.  Afterwards the inference path (folded BN, fused-trunk tiles) is rebuilt
+        from the trained weights."""
+        if not self.compiled:
+            raise RuntimeError("ChessModel was built with compile_model=False")
+        from .train import Trainer
+        if self._trainer is None:
+            self._trainer = Trainer(self.weights, self.device)
+        log = None
+        if logdir is not None:
+            import json
+            import os
+            os.makedirs(logdir, exist_ok=True)
+
+            def log(summary):
+                with open(os.path.join(logdir, "train_log.jsonl"), "a") as f:
+                    f.write(json.dumps(summary) + "\n")
+        history = self._trainer.fit_generator(generator, epochs=epochs, val_gen=val_gen,
+                                              verbose=verbose, log=log)
+        self.load_dict(self._trainer.weights())
+        return history
 
     def save_weights(self, weights_path):
         np.savez(weights_path, **self.weights)

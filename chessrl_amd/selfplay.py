@@ -9,9 +9,10 @@ boundaries so the batch stays full, records gathered across ranks at the end
 stream (colour, Dirichlet noise) is keyed by the GLOBAL game id, so what a game plays
 does not depend on the number of GPUs.
 
-The training half of the reference's ``main`` (selfplay.py:98-108,157-163) is out of
-scope; the CLI keeps ``modeldir --games --threads --debug`` and adds the knobs the
-reference hard-codes (``--sims`` 900 in selfplay.py:76, net size, parallel games).
+``train_model_job`` is the training half of the reference's ``main`` (selfplay.py:98-108,
+157-163): one epoch over the games just played, one batch per game.
+The CLI keeps ``modeldir --games --threads --debug`` and adds the knobs the reference hard-codes
+(``--sims`` 900 in selfplay.py:76, net size, parallel games, ``--rounds`` of play+train).
 """
 import argparse
 import logging
@@ -175,9 +176,23 @@ class SelfPlayRunner(object):
         self.engine.close()
 
 
+def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=1):
+    """selfplay.py:98-108: train on the recorded games and save the weights.  ``records`` are
+    ``GameRecord``s (or ``Game``s): anything with ``get_history()``."""
+    from .dataset import DatasetGame
+    from .netencoder import DataGameSequence
+    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0])
+    if len(data_train) == 0:
+        return None
+    gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
+    history = model.train_generator(gen, epochs=epochs, logdir=model_dir)
+    model.save_weights(model_path)
+    return history
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser(description="Plays self-play chess games on MI355X GPUs and "
-                                     "stores the game records.")
+    parser = argparse.ArgumentParser(description="Plays self-play chess games on MI355X GPUs, "
+                                     "stores the game records and trains the model on them.")
     parser.add_argument("model_dir", metavar="modeldir",
                         help="where to load the model from and store the records")
     parser.add_argument("--games", type=int, default=1)
@@ -190,6 +205,8 @@ def main(argv=None):
     parser.add_argument("--filters", type=int, default=256)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--no-noise", action="store_true")
+    parser.add_argument("--rounds", type=int, default=1, help="play --games games, train, repeat")
+    parser.add_argument("--no-train", action="store_true", help="only play and store the records")
     args = parser.parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO)
 
@@ -206,22 +223,38 @@ def main(argv=None):
     os.makedirs(args.model_dir, exist_ok=True)
     path = get_model_path(args.model_dir)
     weights = path if os.path.exists(path) else None
-    model = ChessModel(weights=weights, blocks=args.blocks, filters=args.filters,
-                       device="cuda:%d" % local, seed=args.seed)
+    model = ChessModel(compile_model=not args.no_train, weights=weights, blocks=args.blocks,
+                       filters=args.filters, device="cuda:%d" % local, seed=args.seed)
     per_rank = (args.games + world - 1) // world
     parallel = args.parallel or min(per_rank, 4096)
-    runner = SelfPlayRunner(model, parallel, args.sims, seed=args.seed, noise=not args.no_noise,
-                            rank=rank, world=world, device=local, total_games=args.games)
-    t0 = time.perf_counter()
-    recs = runner.run()
-    dt = time.perf_counter() - t0
-    log.info("rank %d: %d games, %d sims in %.1fs (%.0f sims/s)", rank, len(recs), runner.sims_run,
-             dt, runner.sims_run / max(dt, 1e-9))
-    allrecs = gather_records(recs, runner.max_plies)
-    if rank == 0:
-        with open(os.path.join(args.model_dir, "gameplays.json"), "w") as f:
-            f.write(dumps(allrecs))
-        log.info("wrote %d game records", len(allrecs))
+    allrecs = []
+    for rnd in range(args.rounds):
+        runner = SelfPlayRunner(model, parallel, args.sims, seed=args.seed + rnd * args.games,
+                                noise=not args.no_noise, rank=rank, world=world, device=local,
+                                total_games=args.games)
+        t0 = time.perf_counter()
+        recs = runner.run()
+        dt = time.perf_counter() - t0
+        log.info("round %d rank %d: %d games, %d sims in %.1fs (%.0f sims/s)", rnd, rank, len(recs),
+                 runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))
+        newrecs = gather_records(recs, runner.max_plies)
+        runner.close()
+        allrecs += newrecs
+        if rank == 0:
+            with open(os.path.join(args.model_dir, "gameplays.json"), "w") as f:
+                f.write(dumps(allrecs))
+            log.info("wrote %d game records", len(allrecs))
+        if not args.no_train:
+            # the reference trains in ONE process; here rank 0 trains on every rank's games and the
+            # new weights go to the other ranks over RCCL (one broadcast per round)
+            if rank == 0:
+                t0 = time.perf_counter()
+                hist = train_model_job(model, newrecs, path, args.model_dir)
+                log.info("round %d: trained on %d games in %.1fs: %s", rnd, len(newrecs),
+                         time.perf_counter() - t0, hist[-1] if hist else None)
+            if world > 1:
+                from .train import broadcast_weights
+                model.load_dict(broadcast_weights(model.weights, "cuda:%d" % local, src=0))
     if world > 1:
         dist.destroy_process_group()
 

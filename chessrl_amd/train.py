@@ -1,0 +1,273 @@
+"""Training step of the tower -- PyTorch-ROCm, fp32.
+
+Mirror of what the reference does between two self-play games
+(/root/reference/src/chessrl/selfplay.py:98-108 -> agent.py:64-89 -> model.py:69-72,83-99):
+``Adam(lr=0.002)`` on ``categorical_crossentropy(policy) + mean_squared_error(value)`` plus the
+``kernel_regularizer='l2'`` (= ``l2(0.01)``) term of every conv / dense kernel (model.py:33-58,
+113-118), BatchNormalization in training mode (batch statistics, eps 1e-3, momentum 0.99), one
+batch = the augmented positions of ``batch_size`` games.
+
+Keras semantics restated here (TensorFlow is absent in this image: *from recollection*; the
+tests hold this module to an independently written CPU restatement of the same step):
+  * crossentropy on probabilities: ``p / sum(p)``, clipped to [1e-7, 1 - 1e-7], ``-sum(t * log p)``,
+    mean over the batch;
+  * BN moving statistics: ``moving = 0.99 * moving + 0.01 * batch``, the moving variance from the
+    UNBIASED batch variance (TF fused batch norm), normalisation by the biased one;
+  * Adam (TF2 ``optimizer_v2``): ``lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)``,
+    ``w -= lr_t * m / (sqrt(v) + 1e-7)`` -- epsilon is NOT bias-corrected, unlike ``torch.optim.Adam``,
+    so the update is written out here.
+The trained weights go back into the self-play path through ``ChessModel.load_dict`` (BN folded,
+fp16 tiles repacked for the fused HIP trunk).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .model import BN_EPS, IN_PLANES, N_POLICY, PAD_PLANES
+
+L2 = 0.01                 # keras.regularizers.l2 default, what the string 'l2' resolves to
+BN_MOMENTUM = 0.99        # keras.layers.BatchNormalization default
+ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 0.002, 0.9, 0.999, 1e-7
+CCE_EPS = 1e-7            # keras.backend.epsilon()
+
+
+class TrainTower(nn.Module):
+    """The tower with its BatchNorm layers unfolded, fp32, NHWC activations."""
+
+    def __init__(self, blocks, filters):
+        super().__init__()
+        self.blocks_n, self.filters = blocks, filters
+
+        def bn(c):
+            return nn.BatchNorm2d(c, eps=BN_EPS, momentum=1.0 - BN_MOMENTUM)
+        self.stem = nn.Conv2d(PAD_PLANES, filters, 3, padding=1)
+        self.conv1 = nn.ModuleList([nn.Conv2d(filters, filters, 3, padding=1) for _ in range(blocks)])
+        self.bn1 = nn.ModuleList([bn(filters) for _ in range(blocks)])
+        self.conv2 = nn.ModuleList([nn.Conv2d(filters, filters, 3, padding=1) for _ in range(blocks)])
+        self.bn2 = nn.ModuleList([bn(filters) for _ in range(blocks)])
+        self.policy_conv, self.policy_bn = nn.Conv2d(filters, 2, 1), bn(2)
+        self.policy_fc = nn.Linear(128, N_POLICY)
+        self.value_conv, self.value_bn = nn.Conv2d(filters, 1, 1), bn(1)
+        self.value_fc1 = nn.Linear(64, 256)
+        self.value_fc2 = nn.Linear(256, 1)
+
+    # ---- Keras-layout dict <-> parameters ----------------------------------------------------
+    def _convs(self):
+        yield "stem", self.stem, None
+        for i in range(self.blocks_n):
+            yield "block%d.conv1" % i, self.conv1[i], ("block%d.bn1" % i, self.bn1[i])
+            yield "block%d.conv2" % i, self.conv2[i], ("block%d.bn2" % i, self.bn2[i])
+        yield "policy.conv", self.policy_conv, ("policy.bn", self.policy_bn)
+        yield "value.conv", self.value_conv, ("value.bn", self.value_bn)
+
+    def _denses(self):
+        yield "policy.dense", self.policy_fc
+        yield "value.dense1", self.value_fc1
+        yield "value.dense2", self.value_fc2
+
+    @torch.no_grad()
+    def load_keras_dict(self, w):
+        def t(a):
+            return torch.from_numpy(np.asarray(a, np.float32))
+        for name, conv, bn in self._convs():
+            k = t(w[name + ".kernel"]).permute(3, 2, 0, 1)                # HWIO -> OIHW
+            if name == "stem":
+                kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
+                kp[:, :IN_PLANES] = k
+                k = kp
+            conv.weight.copy_(k)
+            conv.bias.copy_(t(w[name + ".bias"]))
+            if bn is not None:
+                bname, m = bn
+                m.weight.copy_(t(w[bname + ".gamma"]))
+                m.bias.copy_(t(w[bname + ".beta"]))
+                m.running_mean.copy_(t(w[bname + ".mean"]))
+                m.running_var.copy_(t(w[bname + ".var"]))
+        for name, fc in self._denses():
+            fc.weight.copy_(t(w[name + ".kernel"]).t())
+            fc.bias.copy_(t(w[name + ".bias"]))
+
+    @torch.no_grad()
+    def to_keras_dict(self):
+        w = {}
+        for name, conv, bn in self._convs():
+            k = conv.weight.detach().float().cpu()
+            if name == "stem":
+                k = k[:, :IN_PLANES]
+            w[name + ".kernel"] = k.permute(2, 3, 1, 0).contiguous().numpy()
+            w[name + ".bias"] = conv.bias.detach().cpu().numpy().copy()
+            if bn is not None:
+                bname, m = bn
+                w[bname + ".gamma"] = m.weight.detach().cpu().numpy().copy()
+                w[bname + ".beta"] = m.bias.detach().cpu().numpy().copy()
+                w[bname + ".mean"] = m.running_mean.cpu().numpy().copy()
+                w[bname + ".var"] = m.running_var.cpu().numpy().copy()
+        for name, fc in self._denses():
+            w[name + ".kernel"] = fc.weight.detach().cpu().t().contiguous().numpy()
+            w[name + ".bias"] = fc.bias.detach().cpu().numpy().copy()
+        w["meta.blocks"] = np.array(self.blocks_n)
+        w["meta.filters"] = np.array(self.filters)
+        return w
+
+    def regularized(self):
+        """Every kernel carrying ``kernel_regularizer='l2'`` (all convs and denses, not biases/BN)."""
+        return [c.weight for _, c, _ in self._convs()] + [fc.weight for _, fc in self._denses()]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    # Training batches are whole games, so every batch has a different number of positions.  MIOpen
+    # looks up / compiles solvers per (batch, shape) for forward, backward-data and backward-weights
+    # (measured: ~1.5 s for every new batch size), so the convolutions are written as what they are
+    # on an 8x8 board: a [B*64, 9*Cin] x [9*Cin, Cout] GEMM over the NHWC activations (im2col by nine
+    # shifted views of the zero-padded board), which rocBLAS/hipBLASLt run for any B; autograd gives
+    # the two backward GEMMs.  BatchNorm runs over the flattened [B*64, C] rows.
+    @staticmethod
+    def _conv3x3(x, conv):
+        """x [B,8,8,Cin] -> [B,8,8,Cout]; kernel OIHW viewed as [(ky,kx,c), o]."""
+        b, cin = x.shape[0], x.shape[3]
+        xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+        cols = torch.cat([xp[:, dy:dy + 8, dx:dx + 8, :] for dy in range(3) for dx in range(3)], dim=-1)
+        wm = conv.weight.permute(2, 3, 1, 0).reshape(9 * cin, -1)
+        return torch.addmm(conv.bias, cols.reshape(b * 64, 9 * cin), wm).view(b, 8, 8, -1)
+
+    @staticmethod
+    def _conv1x1(x, conv):
+        b = x.shape[0]
+        return torch.addmm(conv.bias, x.reshape(b * 64, -1), conv.weight.view(conv.weight.shape[0], -1).t()
+                           ).view(b, 8, 8, -1)
+
+    @staticmethod
+    def _bn(x, m):
+        c = x.shape[-1]
+        return F.batch_norm(x.reshape(-1, c), m.running_mean, m.running_var, m.weight, m.bias,
+                            m.training, m.momentum, m.eps).view(x.shape)
+
+    def forward(self, planes):
+        """planes: [B,8,8,128] NHWC (the encoder kernel's buffer, any float dtype).
+        Returns (policy probabilities [B,1968], value [B,1])."""
+        x = self._conv3x3(planes.float(), self.stem)         # no BN / activation (model.py:33-34)
+        for c1, b1, c2, b2 in zip(self.conv1, self.bn1, self.conv2, self.bn2):
+            y = F.relu(self._bn(self._conv3x3(x, c1), b1))
+            y = self._bn(self._conv3x3(y, c2), b2)
+            x = F.relu(x + y)
+        b = x.shape[0]
+        p = F.relu(self._bn(self._conv1x1(x, self.policy_conv), self.policy_bn)).reshape(b, 128)
+        p = torch.softmax(self.policy_fc(p), dim=-1)         # Keras Flatten order (h, w, c)
+        v = F.relu(self._bn(self._conv1x1(x, self.value_conv), self.value_bn)).reshape(b, 64)
+        v = torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
+        return p, v
+
+
+def keras_losses(policy, value, move_index, result, regularized):
+    """(total, policy crossentropy, value mse, l2 term) as Keras reports them."""
+    p = policy / policy.sum(dim=-1, keepdim=True)
+    p = p.clamp(CCE_EPS, 1.0 - CCE_EPS)
+    cce = -torch.log(p.gather(1, move_index.view(-1, 1))[:, 0]).mean()
+    mse = ((value[:, 0] - result) ** 2).mean()
+    reg = sum(L2 * (k * k).sum() for k in regularized)
+    return cce + mse + reg, cce, mse, reg
+
+
+class KerasAdam(object):
+    """TF2 Keras ``Adam`` (see module docstring), fused over all tensors with ``torch._foreach``."""
+
+    def __init__(self, params, lr=ADAM_LR, beta_1=ADAM_B1, beta_2=ADAM_B2, epsilon=ADAM_EPS):
+        self.params = [p for p in params]
+        self.lr, self.b1, self.b2, self.eps = lr, beta_1, beta_2, epsilon
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        # m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+        torch._foreach_mul_(self.m, self.b1)
+        torch._foreach_add_(self.m, grads, alpha=1.0 - self.b1)
+        torch._foreach_mul_(self.v, self.b2)
+        torch._foreach_addcmul_(self.v, grads, grads, value=1.0 - self.b2)
+        lr_t = self.lr * float(np.sqrt(1.0 - self.b2 ** self.t)) / (1.0 - self.b1 ** self.t)
+        denom = torch._foreach_sqrt(self.v)
+        torch._foreach_add_(denom, self.eps)
+        torch._foreach_addcdiv_(self.params, self.m, denom, value=-lr_t)
+
+
+class Trainer(object):
+    """Holds the unfolded fp32 tower, the optimizer state and runs ``fit_generator``-style epochs."""
+
+    def __init__(self, weights, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("training needs an MI355X (no CPU fallback in the product path)")
+        self.net = TrainTower(int(weights["meta.blocks"]), int(weights["meta.filters"]))
+        self.net.load_keras_dict(weights)
+        self.net.to(self.device).train()
+        self.opt = KerasAdam(self.net.parameters())
+
+    def train_on_batch(self, planes, move_index, result):
+        """One optimizer step; returns dict(loss, policy_loss, value_loss, reg_loss, accuracy)."""
+        self.net.train()
+        self.opt.zero_grad()
+        policy, value = self.net(planes)
+        total, cce, mse, reg = keras_losses(policy, value, move_index, result, self.net.regularized())
+        total.backward()
+        self.opt.step()
+        acc = (policy.argmax(dim=-1) == move_index).float().mean()
+        return {"loss": total.item(), "policy_out_loss": cce.item(), "value_out_loss": mse.item(),
+                "reg_loss": reg.item(), "policy_out_accuracy": acc.item()}
+
+    @torch.no_grad()
+    def evaluate(self, planes, move_index, result):
+        self.net.eval()
+        policy, value = self.net(planes)
+        total, cce, mse, reg = keras_losses(policy, value, move_index, result, self.net.regularized())
+        self.net.train()
+        return {"loss": total.item(), "policy_out_loss": cce.item(), "value_out_loss": mse.item()}
+
+    def fit_generator(self, generator, epochs=1, val_gen=None, verbose=0, log=None):
+        """Keras ``fit_generator`` on a ``Sequence``: every batch once per epoch, batch order
+        shuffled by the global ``np.random`` (Sequence default ``shuffle=True``)."""
+        history = []
+        for epoch in range(epochs):
+            order = np.random.permutation(len(generator))
+            logs = []
+            for idx in order:
+                planes, move_index, result = generator.device_batch(int(idx), self.device)
+                logs.append(self.train_on_batch(planes, move_index, result))
+            summary = {k: float(np.mean([l[k] for l in logs])) for k in logs[0]} if logs else {}
+            if val_gen is not None and len(val_gen) > 0:
+                vl = [self.evaluate(*val_gen.device_batch(i, self.device)) for i in range(len(val_gen))]
+                summary.update({"val_" + k: float(np.mean([l[k] for l in vl])) for k in vl[0]})
+            summary["epoch"] = epoch
+            history.append(summary)
+            if log is not None:
+                log(summary)
+            if verbose:
+                print("epoch %d: %s" % (epoch, summary))
+        return history
+
+    def weights(self):
+        return self.net.to_keras_dict()
+
+
+def broadcast_weights(weights, device, src=0):
+    """All ranks end up with rank ``src``'s weight dict: ONE flat fp32 broadcast over RCCL (the only
+    collective of a play+train round besides the record gather)."""
+    import torch.distributed as dist
+    names = sorted(k for k in weights if not k.startswith("meta."))
+    flat = torch.cat([torch.from_numpy(np.asarray(weights[k], np.float32)).reshape(-1) for k in names])
+    flat = flat.to(device) if dist.get_backend() == "nccl" else flat
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu().numpy()
+    out, off = {k: weights[k] for k in weights if k.startswith("meta.")}, 0
+    for k in names:
+        shape = np.asarray(weights[k]).shape
+        n = int(np.prod(shape))
+        out[k] = flat[off:off + n].reshape(shape).copy()
+        off += n
+    return out

@@ -40,3 +40,31 @@ def test_gather_records_single_process_is_identity():
     from chessrl_amd import records
     recs = [records.GameRecord(5, [1, 2], 0, True), records.GameRecord(1, [3], 1, False)]
     assert [r.game_id for r in records.gather_records(recs, 8)] == [1, 5]
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd.model import init_weights
+    from chessrl_amd.train import broadcast_weights
+    w = init_weights(1, 16, seed=100 + rank)                     # every rank starts different
+    out = broadcast_weights(w, "cpu", src=0)
+    ref = init_weights(1, 16, seed=100)
+    q.put((rank, all(np.array_equal(out[k], ref[k]) for k in ref), sorted(out) == sorted(ref)))
+    dist.destroy_process_group()
+
+
+def test_trained_weights_broadcast_two_ranks():
+    """After rank 0 trained, every rank holds rank 0's weights (one flat broadcast)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok and keys for _, ok, keys in got)
