@@ -159,9 +159,10 @@ int  crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const vo
                           const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
                           const void *dev_head_w_f32, const void *dev_head_b_f32,
                           void *dev_head_out_f32);
-/* The same for `filters` in {128, 256} (256 = BASELINE config C5, the reference's own width,
- * model.py:33).  Tiles are always 16 KiB: [filters out][KT in] with KT = 64 (128 filters) or 32
- * (256 filters), consumption order [conv][tap][in-ch/KT]; the stem has 128 input channels, every
+/* The same for `filters` in {64, 128, 256} (BASELINE configs C2, C3/C4, C5; 256 is the
+ * reference's own width, model.py:33).  Tiles are [filters out][KT in] with KT = 64 (64 and 128
+ * filters: 8 / 16 KiB) or 32 (256 filters: 16 KiB), consumption order [conv][tap][in-ch/KT]; the
+ * stem has 128 input channels, every
  * other conv `filters`.  Biases [1+2*n_blocks][filters], head weights [3][filters], trunk output
  * [n_boards][8][8][filters]. */
 int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
