@@ -60,12 +60,12 @@ class DataGameSequence(object):
     def __len__(self):
         return int(len(self.dataset) / self.batch_size)
 
-    def _context(self, n):
-        if self._ctx is None or self._ctx.G < n:
+    def _context(self, n, device=0):
+        if self._ctx is None or self._ctx.G < n or self._ctx.device != device:
             if self._ctx is not None:
                 self._ctx.close()
-            self._ctx = _lib.Context(max_games=(n + 63) // 64 * 64, max_sims=1,
-                                     max_plies=max(64, n + 8))
+            cap = (n + 63) // 64 * 64          # a sample sits at most n - 1 <= cap plies deep
+            self._ctx = _lib.Context(max_games=cap, max_sims=1, max_plies=cap + 8, device=device)
         self._ctx.set_window(0, self._ctx.n_slots)
         return self._ctx
 
@@ -93,7 +93,7 @@ class DataGameSequence(object):
         if n == 0:
             return (torch.zeros((0, 8, 8, _lib.PLANES), dtype=torch.float16, device=dev),
                     torch.zeros(0, dtype=torch.int64, device=dev), torch.zeros(0, device=dev))
-        ctx = self._context(n)
+        ctx = self._context(n, dev.index or 0)
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctx.reset_games()
         depth = np.array(depth)

@@ -137,3 +137,28 @@ def test_dataset_roundtrip_and_reference_shaped_play_game(tmp_path):
     assert len(d3) == 2
     for g in aug:
         g["game"].free()
+
+
+def test_cli_plays_and_trains_rounds(tmp_path):
+    """``python -m chessrl_amd.selfplay modeldir --games N`` (selfplay.py:112-163): two rounds of
+    play + train; records, weights and the training log land in modeldir."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "models")
+    cmd = [sys.executable, "-m", "chessrl_amd.selfplay", d, "--games", "6", "--sims", "4",
+           "--blocks", "1", "--filters", "64", "--rounds", "2", "--seed", "5"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = json.load(open(os.path.join(d, "gameplays.json")))
+    assert len(recs) == 12 and all(g["result"] in (1, -1, 0) and len(g["moves"]) > 0 for g in recs)
+    log = [json.loads(l) for l in open(os.path.join(d, "train_log.jsonl"))]
+    assert len(log) == 2 and all(np.isfinite(e["loss"]) for e in log)
+    w = dict(np.load(os.path.join(d, "model-0.npz")))
+    assert int(w["meta.blocks"]) == 1 and int(w["meta.filters"]) == 64
+    # a second invocation picks the saved model up (get_model_path) and only plays
+    r = subprocess.run(cmd[:-4] + ["--no-train"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(dict(np.load(os.path.join(d, "model-0.npz")))["stem.kernel"], w["stem.kernel"])
