@@ -242,9 +242,10 @@ def main():
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused), "parallelism": "games sharded, no collective on the hot path"},
             "moves_per_sec": total_sims / max_dt / a.sims,
-            # games/hour: a random-init 10x128 net plays 190 moves (380 plies) per game on average
-            # (512 complete games, profiles/r01/game_length_c3net_50sims.json); assumption stated
-            "self_play_games_per_hour_est": total_sims / max_dt / a.sims / 190.0 * 3600.0,
+            # games/hour: a random-init 10x128 net at 800 sims/move plays 165.5 moves (331 plies) per
+            # game on average (512 complete games, profiles/r01/game_length_c3net_800sims.json;
+            # 190 moves at 50 sims/move); steady state with refill = moves/s / moves per game
+            "self_play_games_per_hour_est": total_sims / max_dt / a.sims / 165.5 * 3600.0,
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
             "roofline": roof, "roofline_tree": tree,

@@ -162,3 +162,36 @@ def test_cli_plays_and_trains_rounds(tmp_path):
     r = subprocess.run(cmd[:-4] + ["--no-train"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(dict(np.load(os.path.join(d, "model-0.npz")))["stem.kernel"], w["stem.kernel"])
+
+
+@pytest.mark.parametrize("agent_white", [False, True])
+def test_game_agent_interactive_surface(agent_white):
+    """GameAgent (gameagent.py:7-50): every human move is answered by the agent's greedy move."""
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.gameagent import GameAgent
+    net = FakeNet(seed=41, prior_shift=30)
+    agent = Agent(agent_white, model=net.to("cuda:0"))
+    oagent = mcts_oracle.OracleAgent(net)
+    g = GameAgent(agent, player_color=not agent_white)
+    og = OracleGame()
+    rng = np.random.default_rng(12)
+    if agent_white:
+        assert g.move("a7a6") is True and len(g) == 1     # the argument is ignored: agent opens
+        og.move(oagent.best_move(og, real_game=True))
+    for _ in range(30):
+        if og.get_result() is not None:
+            break
+        assert g.move("a1a1") is False and len(g) == len(og)   # illegal: ignored
+        lm = og.get_legal_moves()
+        mv = lm[int(rng.integers(len(lm)))]
+        assert g.move(mv) is True
+        og.move(mv)
+        if og.get_result() is None:
+            og.move(oagent.best_move(og, real_game=True))
+        assert g.get_history()["moves"] == og.get_history()["moves"]
+    c = g.get_copy()
+    assert isinstance(c, GameAgent) and c.get_history()["moves"] == g.get_history()["moves"]
+    with pytest.raises(ValueError):
+        GameAgent(None)
+    c.free()
+    g.tearup()
