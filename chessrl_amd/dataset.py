@@ -28,11 +28,18 @@ class DatasetGame(object):
             g.move(m)
         return augmented
 
-    def load(self, path):
+    def load(self, path, slot_free=False):
         with open(path, "r") as f:
-            self.loads(f.read())
+            self.loads(f.read(), slot_free=slot_free)
 
-    def loads(self, string):
+    def loads(self, string, slot_free=False):
+        """dataset.py:50-57.  ``slot_free=True`` keeps the games as ``GameRecord``s (no device
+        slot per game: training sets larger than the 512-slot ``Game`` arena); the moves are then
+        replayed -- and checked -- on the device when a batch is built."""
+        if slot_free:
+            from . import records
+            self.games.extend(r for r in records.loads(string) if len(r) > 0)
+            return
         for item in json.loads(string):
             g = game.Game(date=item["date"], player_color=item["player_color"])
             if len(item["moves"]) > 0:

@@ -288,3 +288,27 @@ def test_agent_train_on_a_self_played_game_updates_the_search_path(tmp_path):
     assert a == b
     for g in d.games + [gam, g0]:
         g.free()
+
+
+@pytest.mark.gpu
+def test_supervised_cli_trains_on_a_json_dataset(tmp_path):
+    """supervised.py:37-62: DatasetGame JSON -> Agent.train(validation_split=0.25, batch_size) -> save."""
+    import json
+    from chessrl_amd import supervised
+    games = []
+    for s in range(8):
+        g = _random_game(50 + s, 20 + 3 * s)
+        games.append({"moves": g.get_history()["moves"], "result": (s % 3) - 1, "player_color": bool(s & 1),
+                      "date": "02/10/2026 00:00:00"})
+    games.append({"moves": [], "result": None, "player_color": True, "date": None})      # dropped on load
+    data = tmp_path / "gameplays.json"
+    data.write_text(json.dumps(games))
+    mdir = str(tmp_path / "model")
+    np.random.seed(0)
+    hist = supervised.train(mdir, str(data), epochs=2, batch_size=2, blocks=1, filters=64)
+    assert len(hist) == 2 and all(np.isfinite(h["loss"]) and np.isfinite(h["val_loss"]) for h in hist)
+    assert hist[1]["loss"] < hist[0]["loss"]
+    w0 = dict(np.load(mdir + "/model-0.npz"))
+    supervised.main([mdir, str(data), "--bs", "3"])           # picks model-0.npz up and continues
+    w1 = dict(np.load(mdir + "/model-0.npz"))
+    assert int(w1["meta.filters"]) == 64 and np.abs(w1["stem.kernel"] - w0["stem.kernel"]).max() > 0
