@@ -196,7 +196,10 @@ def main():
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
             k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (
-                "k_trunk128_pipe<0>" if F == 128 else "k_trunk_gen<%d>" % F, B, G)
+                # the dispatch rule of crl_trunk_forward (csrc/api.hip)
+                ("k_trunk_gen<%d, %d>" % (F, (1 if F == 256 else 2)) if G <= 128 * (2 if F == 256 else 4)
+                 else "k_trunk128_pipe<0>" if F == 128 else "k_trunk_gen<%d, %d>" % (F, 2 if F == 256 else 4)),
+                B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats

@@ -484,14 +484,21 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
     kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production, 128 filters
     int lds_bytes = crl_tower::P2_LDS_BYTES;
     int boards_per_wg = crl_tower::BOARDS_PER_WG;
+    // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
+    // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
+    const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && !getenv("CRL_TRUNK_NO_SMALL");
+#define CRL_GEN(F_, NB_)                                                                        \
+    do {                                                                                         \
+        kern = crl_tower::k_trunk_gen<F_, NB_>;                                                  \
+        lds_bytes = crl_tower::Geo<F_, NB_>::LDS_BYTES;                                          \
+        boards_per_wg = NB_;                                                                     \
+    } while (0)
     if (filters == 256) {
-        kern = crl_tower::k_trunk_gen<256>;
-        lds_bytes = crl_tower::Geo<256>::LDS_BYTES;
-        boards_per_wg = crl_tower::Geo<256>::NB;
+        if (small) CRL_GEN(256, 1); else CRL_GEN(256, 2);
     } else if (filters == 64) {
-        kern = crl_tower::k_trunk_gen<64>;
-        lds_bytes = crl_tower::Geo<64>::LDS_BYTES;
-        boards_per_wg = crl_tower::Geo<64>::NB;
+        if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4);
+    } else if (small) {
+        CRL_GEN(128, 2);
     } else if (const char *ev = getenv("CRL_TRUNK_VARIANT")) {
         // tuning / timing-only builds of the 128-filter kernel (tools/trunk_bench.py; the ladder in
         // profiles/r01/pmc_trunk_kernel.md).  Unset or 0 = production.
@@ -512,10 +519,11 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
         case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
         case 204: kern = crl_tower::k_trunk128_pipe<4>; break;                 // staggered staging
-        case 300: kern = crl_tower::k_trunk_gen<128>; lds_bytes = crl_tower::Geo<128>::LDS_BYTES; break;
+        case 300: CRL_GEN(128, 4); break;                                      // the template at F = 128
         default: break;
         }
     }
+#undef CRL_GEN
     // opt in to > 64 KiB of dynamic LDS once per kernel
     static std::vector<const void *> lds_ready;
     bool seen = false;

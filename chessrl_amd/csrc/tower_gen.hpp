@@ -5,11 +5,16 @@
 // 20x256) runs on a hand-written kernel.  F = 128 is normally served by the hand-tuned
 // tower_pipe.hpp (3.5 % faster than this template at F = 128).
 //
-// Geometry per workgroup (512 threads, 8 waves, 2 per SIMD):
-//   F    boards  waves/board     wave tile      act. row   weight tile [F out][KT in]  sub-steps/tile
-//   64     4     2 (pos halves)  32 pos x 64 ch   272 B     64 x 64   ( 8 KiB)             4
-//   128    4     2 (ch halves)   64 pos x 64 ch   272 B    128 x 64   (16 KiB)             4
-//   256    2     4 (ch quarters) 64 pos x 64 ch   528 B    256 x 32   (16 KiB)             2
+// Geometry per workgroup (512 threads, 8 waves, 2 per SIMD), Geo<F, NB> with NB boards resident:
+//   F    NB  waves/board               wave tile        act. row  weight tile [F out][KT in]  sub-steps/tile
+//   64    4  2 (position halves)       32 pos x 64 ch    272 B     64 x 64   ( 8 KiB)           4
+//   128   4  2 (channel halves)        64 pos x 64 ch    272 B    128 x 64   (16 KiB)           4
+//   256   2  4 (channel quarters)      64 pos x 64 ch    528 B    256 x 32   (16 KiB)           2
+// and, for batches too small to give every CU a workgroup (<= 128 workgroups of the above), the
+// same kernels with half the boards per workgroup and twice the workgroups:
+//   64    2  4 (pos halves x ch halves) 32 pos x 32 ch
+//   128   2  4 (pos halves x ch halves) 32 pos x 64 ch
+//   256   1  8 (pos halves x ch quarters) 32 pos x 64 ch
 // The stem reads the 128 input planes (channels 0..127 of the row; rows are at least 128 channels
 // wide), every other layer F channels.  Biases are staged per layer (F floats).
 #pragma once
@@ -17,13 +22,16 @@
 
 namespace crl_tower {
 
-template <int F>
+template <int F, int NB_>
 struct Geo {
     static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
-    static constexpr int NQ = F / 64;                   // 64-channel groups
-    static constexpr int PH = F == 64 ? 2 : 1;          // position halves (waves splitting a board)
+    static constexpr int NB = NB_;                      // boards per workgroup
+    static constexpr int WPB = 8 / NB;                  // waves per board
+    static constexpr int NT = (F == 64 && NB == 2) ? 1 : 2;     // 32-channel tiles per wave
+    static constexpr int CG = F / (32 * NT);            // channel groups (waves splitting the channels)
+    static constexpr int PH = WPB / CG;                 // position halves (waves splitting a board)
     static constexpr int MT = 2 / PH;                   // 32-position tiles per wave
-    static constexpr int NB = 8 / (NQ * PH);            // boards per workgroup
+    static_assert(NB * CG * PH == 8 && (PH == 1 || PH == 2), "8 waves per workgroup");
     static constexpr int KT = F == 256 ? 32 : 64;       // input channels per weight tile
     static constexpr int SPT = KT / 16;                 // 16-channel sub-steps per tile
     static constexpr int WROW = KT * 2;                 // bytes per weight-tile row
@@ -51,10 +59,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-template <int F>
+template <class G>
 __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, int t, int tid)
 {
-    typedef Geo<F> G;
     const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
     lds_byte *dst = lds + G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
     const int wave_base = tid & ~63;
@@ -73,7 +80,7 @@ __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, 
 //   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
-template <int F>
+template <int F, int NB>
 __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -82,24 +89,24 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                                                        const float *__restrict__ head_b,
                                                        float *__restrict__ head_out)
 {
-    typedef Geo<F> G;
-    constexpr int MT = G::MT;
+    typedef Geo<F, NB> G;
+    constexpr int MT = G::MT, NT = G::NT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
     const int lds_base = (int)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int board = wave / (G::NQ * G::PH);
-    const int nq = (wave / G::PH) % G::NQ;              // 64-channel group of this wave
-    const int pbase = 32 * (wave % G::PH);              // first position of this wave (F = 64 only)
+    const int board = wave / G::WPB;
+    const int obase = (32 * NT) * ((wave / G::PH) % G::CG);      // first output channel of this wave
+    const int pbase = 32 * (wave % G::PH);              // first position of this wave
     const int r = lane & 31, h = lane >> 5;
     const int n_convs = 1 + 2 * n_blocks;
     const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
-    stage_wtile_gen<F>(wts, lds, 0, tid);
-    stage_wtile_gen<F>(wts, lds, 1, tid);
-    stage_wtile_gen<F>(wts, lds, 2, tid);
+    stage_wtile_gen<G>(wts, lds, 0, tid);
+    stage_wtile_gen<G>(wts, lds, 1, tid);
+    stage_wtile_gen<G>(wts, lds, 2, tid);
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
         const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
@@ -123,29 +130,29 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
     int px[MT], py[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) { const int p = pbase + 32 * mt + r; px[mt] = p & 7; py[mt] = p >> 3; }
-    int waddr[2][G::SPT];                               // weight fragment offset inside a tile
+    int waddr[NT][G::SPT];                              // weight fragment offset inside a tile
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const int o = 64 * nq + 32 * nt + r;
+    for (int nt = 0; nt < NT; nt++) {
+        const int o = obase + 32 * nt + r;
 #pragma unroll
         for (int s = 0; s < G::SPT; s++) waddr[nt][s] = o * G::WROW + (((2 * s + h) ^ G::wswz(o)) << 4);
     }
 
-    f32x16 res[MT][2];
+    f32x16 res[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < NT; b++)
 #pragma unroll
             for (int i = 0; i < 16; i++) res[a][b][i] = 0.f;
 
     int t = 0;                                          // tile of the K-step being computed
     for (int conv = 0; conv < n_convs; conv++) {
-        f32x16 acc[MT][2];
+        f32x16 acc[MT][NT];
 #pragma unroll
         for (int a = 0; a < MT; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
+            for (int b = 0; b < NT; b++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
         // this layer's bias: fetched now, parked in LDS just before the epilogue barrier
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++)
+                for (int nt = 0; nt < NT; nt++)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[nt], f.x[mt], acc[mt][nt], 0, 0, 0);
         };
         Frags f0, f1;
@@ -180,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) f.x[mt] = lds_read16_asm<i * 32>(ab[next_tap ? 1 : 0][mt]);
                 const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * G::TILE_BYTES;
-                f.w[0] = lds_read16_asm<0>(wb + waddr[0][i % G::SPT]);
-                f.w[1] = lds_read16_asm<0>(wb + waddr[1][i % G::SPT]);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) f.w[nt] = lds_read16_asm<0>(wb + waddr[nt][i % G::SPT]);
             };
             if (tap == 0) fetch(std::integral_constant<int, 0>{}, false, f0);
             static_for<0, NS>([&](auto IC) {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                     else wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t + 3 < n_tiles) stage_wtile_gen<F>(wts, lds, t + 3, tid);
+                    if (t + 3 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 3, tid);
                 }
                 constexpr bool wrap = i + 1 >= NS;
                 bool issued = false;
@@ -208,10 +215,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                         else fetch(std::integral_constant<int, i + 1>{}, false, f0);
                     }
                 }
-                // operands of THIS sub-step have landed; the MT+2 reads just issued may be in flight
+                // operands of THIS sub-step have landed; the MT+NT reads just issued may be in flight
                 if (!issued) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else if constexpr (MT + NT == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if constexpr (MT + NT == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i % 2 == 0) mfma_all(f0);
                 else mfma_all(f1);
@@ -246,10 +254,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
         for (int mt = 0; mt < MT; mt++) {
             const int p = pbase + 32 * mt + r;
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int o0 = 64 * nq + 32 * nt + 8 * g + 4 * h;
+                    const int o0 = obase + 32 * nt + 8 * g + 4 * h;
                     const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
                         lds + G::BIAS_OFF + o0 * 4);
                     half4 o16;
@@ -276,10 +284,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
         for (int mt = 0; mt < MT; mt++) {
             const int p = pbase + 32 * mt + r;
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++)
+            for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
-                    const int o0 = 64 * nq + 32 * nt + 8 * g + 4 * h;
+                    const int o0 = obase + 32 * nt + 8 * g + 4 * h;
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = res[mt][nt][4 * g + j];
@@ -289,18 +297,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
     }
 
     if (head_out) {
-        // a position's F channels live in NQ waves x 2 lane halves: 2*NQ partial sums per output
-        constexpr int NC = 2 * G::NQ;
+        // a position's F channels live in CG waves x 2 lane halves: 2*CG partial sums per output
+        constexpr int NC = 2 * G::CG;
         float part[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int k = 0; k < 3; k++) part[mt][k] = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const int o0 = 64 * nq + 32 * nt + 8 * g + 4 * h;
+                const int o0 = obase + 32 * nt + 8 * g + 4 * h;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const f32x4 wv = *reinterpret_cast<const f32x4 *>(head_w + k * F + o0);
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                scratch[(((board * 64 + pbase + 32 * mt + r) * 3) + k) * NC + nq * 2 + h] = part[mt][k];
+                scratch[(((board * 64 + pbase + 32 * mt + r) * 3) + k) * NC + (obase / (32 * NT)) * 2 + h] = part[mt][k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int i = tid; i < G::NB * 64 * 3; i += 512) {

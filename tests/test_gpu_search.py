@@ -253,22 +253,34 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, rbn, dtype):
     eng.close()
 
 
+@pytest.mark.parametrize("n_boards", [8, 516])
 @pytest.mark.parametrize("filters", [64, 128, 256])
-def test_fused_trunk_matches_pytorch_trunk_activations(filters):
-    """The fused HIP trunk's fp32 activations vs the fp32 oracle trunk, element by element."""
+def test_fused_trunk_matches_pytorch_trunk_activations(filters, n_boards):
+    """The fused HIP trunk's fp32 activations vs the fp32 oracle trunk, element by element.
+    8 boards run the half-size workgroup geometry (small batches), 516 the full-size one."""
+    import os
     from chessrl_amd.model import ChessModel
     w = tower_oracle.init_weights(3, filters, seed=11, randomize_bn=True)
     model = ChessModel(weights=w)
     ref = ChessModel(weights=w, dtype=torch.float32, fused=False)
     rng = np.random.default_rng(3)
-    planes = torch.zeros((8, 8, 8, 128), dtype=torch.float16, device="cuda:0")
-    planes[..., :127] = torch.from_numpy((rng.random((8, 8, 8, 127)) < 0.15).astype(np.float16)).cuda()
+    planes = torch.zeros((n_boards, 8, 8, 128), dtype=torch.float16, device="cuda:0")
+    planes[..., :127] = torch.from_numpy((rng.random((n_boards, 8, 8, 127)) < 0.15).astype(np.float16)).cuda()
     trunk, heads = model._run_fused(planes, want_trunk=True)
     with torch.no_grad():
         exp = ref.net.trunk(planes.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     scale = exp.abs().max().item()
     assert (trunk - exp).abs().max().item() <= 4e-3 * scale           # fp16 operands, fp32 accumulate
-    assert heads.shape == (8, 192) and (heads >= 0).all()
+    assert heads.shape == (n_boards, 192) and (heads >= 0).all()
+    if n_boards == 8:
+        # both geometries accumulate every output in the same order: identical trunk bits
+        os.environ["CRL_TRUNK_NO_SMALL"] = "1"
+        try:
+            trunk_big, heads_big = model._run_fused(planes, want_trunk=True)
+        finally:
+            del os.environ["CRL_TRUNK_NO_SMALL"]
+        assert torch.equal(trunk, trunk_big)
+        assert (heads - heads_big).abs().max().item() <= 1e-5 * max(1.0, heads.abs().max().item())
 
 
 def test_search_matches_committed_golden_vectors(golden_dir):
