@@ -12,7 +12,7 @@ buffer used in place (channel 127 is a zero pad, so K = 9*128 is a multiple of
 the MFMA K-step); BatchNorm is folded into the preceding conv in fp32 before
 the cast to fp16; softmax / tanh run in fp32.  Weights are exchanged as a flat
 ``name -> ndarray`` dict in Keras layouts (conv HWIO, dense (in,out)), saved as
-``.npz`` (the reference's ``.h5`` needs h5py, absent here).
+``.npz`` or as a Keras ``.h5`` weight file (chessrl_amd/keras_h5.py; no h5py needed).
 """
 import numpy as np
 import torch
@@ -79,6 +79,13 @@ def _fold(w, conv, bn=None):
         k = k * s.view(-1, 1, 1, 1)
         b = (b - mean) * s + beta
     return k, b
+
+
+def _read_weights(path):
+    if str(path).endswith((".h5", ".hdf5")):
+        from .keras_h5 import load_keras_h5
+        return load_keras_h5(path)
+    return dict(np.load(path))
 
 
 class Tower(nn.Module):
@@ -168,7 +175,7 @@ class ChessModel(object):
         self.dtype = dtype
         self.want_fused = fused
         if isinstance(weights, str):
-            weights = dict(np.load(weights))
+            weights = _read_weights(weights)
         if weights is None:
             weights = init_weights(blocks, filters, seed)
         self.load_dict(weights)
@@ -277,7 +284,8 @@ class ChessModel(object):
                 val_out.copy_(v)
 
     def load_weights(self, weights_path):
-        self.load_dict(dict(np.load(weights_path)))
+        """model.py:77-78.  ``.h5`` = a Keras weight file (chessrl_amd/keras_h5.py), else ``.npz``."""
+        self.load_dict(_read_weights(weights_path))
         self._trainer = None                     # optimizer state belongs to the old weights
 
     def train_generator(self, generator, epochs=1, logdir=None, val_gen=None, verbose=0):
@@ -305,7 +313,12 @@ class ChessModel(object):
         return history
 
     def save_weights(self, weights_path):
-        np.savez(weights_path, **self.weights)
+        """model.py:80-81."""
+        if str(weights_path).endswith((".h5", ".hdf5")):
+            from .keras_h5 import save_keras_h5
+            save_keras_h5(self.weights, weights_path)
+        else:
+            np.savez(weights_path, **self.weights)
 
     @torch.no_grad()
     def __call__(self, planes):

@@ -30,9 +30,10 @@ log = logging.getLogger("chessrl_amd.selfplay")
 
 
 def get_model_path(directory):
-    """Newest ``model-<v>.npz`` of a directory (selfplay.py:33-56, with .npz for .h5)."""
+    """Newest ``model-<v>.npz`` / ``model-<v>.h5`` of a directory (selfplay.py:33-56; a fresh
+    directory gets ``model-0.npz``, a directory of Keras ``.h5`` files keeps using ``.h5``)."""
     path = directory + "/model-0.npz"
-    models = [f for f in os.listdir(directory) if f.endswith("npz")]
+    models = [f for f in os.listdir(directory) if f.endswith(("npz", "h5"))]
     if len(models) > 0:
         max_v = max([m.split("-")[1] for m in models])
         m = [model for model in models if model.endswith(max_v)][0]
