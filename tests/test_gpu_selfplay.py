@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import mcts_oracle
-from oracle.chess_oracle import OracleGame, move_to_uci
+from oracle.chess_oracle import OracleGame
 from oracle.fakenet import FakeNet
 
 pytestmark = pytest.mark.gpu

@@ -1,6 +1,5 @@
 """CPU: the C-ABI library loads and exports every declared symbol, fails loudly without a GPU;
 host-side logic (labels, compute_policy, records, conversions, tower BN folding)."""
-import ctypes
 import json
 import os
 import re

@@ -1,6 +1,4 @@
 """Shared helpers for the parity tests (oracle <-> C-ABI conversions)."""
-import numpy as np
-
 from oracle.chess_oracle import OcBoard, OracleGame, board_from_fen, board_to_array  # noqa: F401
 
 PERFT_FENS = {
