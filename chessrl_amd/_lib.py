@@ -28,7 +28,7 @@ FLAG_NUMPY_LEGACY = 1
 SYMBOLS = [
     "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
     "crl_max_sims", "crl_set_window", "crl_copy_game", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
-    "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_results", "crl_records",
+    "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_push_sequences", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
@@ -93,6 +93,7 @@ def lib():
     L.crl_get_positions.argtypes = [vp, vp, i32]
     L.crl_legal_moves.argtypes = [vp, vp, vp]
     L.crl_push_moves.argtypes = [vp, vp, vp]
+    L.crl_push_sequences.argtypes = [vp, vp, vp, i32, vp]
     L.crl_results.argtypes = [vp, vp]
     L.crl_records.argtypes = [vp, vp, vp, vp]
     L.crl_encode.argtypes = [vp, vp]
@@ -199,6 +200,16 @@ class Context(object):
         ok = np.zeros(self.G, dtype=np.uint8)
         self._ck(self._L.crl_push_moves(self._h, _ptr(m), _ptr(ok)), "crl_push_moves")
         return ok
+
+    def push_sequences(self, moves, counts):
+        """Every game replays its own move list (one launch); returns the number applied per game."""
+        m = np.ascontiguousarray(moves, dtype=np.uint16)
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        assert m.ndim == 2 and m.shape[0] == self.G and c.shape == (self.G,)
+        pushed = np.zeros(self.G, dtype=np.int32)
+        self._ck(self._L.crl_push_sequences(self._h, _ptr(m), _ptr(c), m.shape[1], _ptr(pushed)),
+                 "crl_push_sequences")
+        return pushed
 
     def results(self):
         r = np.zeros(self.G, dtype=np.int8)

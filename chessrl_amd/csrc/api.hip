@@ -321,6 +321,32 @@ int crl_push_moves(crl_ctx *ctx, const uint16_t *moves, uint8_t *ok)
     return check_dev_error(ctx);
 }
 
+int crl_push_sequences(crl_ctx *ctx, const uint16_t *moves, const int32_t *counts, int stride,
+                       int32_t *pushed)
+{
+    if (!ctx || !moves || !counts || !pushed || stride < 1)
+        return fail(ctx, CRL_ERR_ARG, "crl_push_sequences: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->W;
+    u16 *dseq = nullptr;                      // setup-time call: a scratch buffer per call is fine
+    HIP_TRY(ctx, hipMalloc((void **)&dseq, G * (size_t)stride * sizeof(u16)));
+    hipError_t e = hipMemcpyAsync(dseq, moves, G * (size_t)stride * sizeof(u16), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ctx->t_i32b, counts, G * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_push_seq, dim3((unsigned)G), dim3(64), 0, ctx->stream, ctx->d, (const u16 *)dseq,
+                           (const int32_t *)ctx->t_i32b, stride, ctx->t_i32c);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(pushed, ctx->t_i32c, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dseq);
+    if (e != hipSuccess) return fail(ctx, CRL_ERR_HIP, hipGetErrorString(e));
+    if (es != hipSuccess) return fail(ctx, CRL_ERR_HIP, hipGetErrorString(es));
+    return check_dev_error(ctx);
+}
+
 int crl_results(crl_ctx *ctx, int8_t *result)
 {
     if (!ctx || !result) return fail(ctx, CRL_ERR_ARG, "crl_results: bad argument");

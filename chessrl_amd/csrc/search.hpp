@@ -292,6 +292,33 @@ __global__ __launch_bounds__(64) void k_push(Dev d, const u16 *moves, uint8_t *o
     if (legal) game_push(d, g, b, mv, lane, s);
 }
 
+// DatasetGame.loads / augment_game (dataset.py:21-57): replay a recorded move list, each move through
+// the same legality test as Game.move; one launch for every game's whole list.
+__global__ __launch_bounds__(64) void k_push_seq(Dev d, const u16 *seq, const int32_t *counts, int stride,
+                                                   int32_t *pushed)
+{
+    __shared__ WaveLds s;
+    const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    const int n = counts[r] < stride ? counts[r] : stride;
+    int i = 0;
+    for (; i < n; i++) {
+        const u32 mv = seq[(size_t)r * stride + i];
+        if (mv == NO_MOVE) break;
+        Board b = d.cur[g];
+        MoveGenInfo mi = wave_movegen(b, lane, s.mv);
+        __syncthreads();
+        bool found = false;
+        for (int j = lane; j < mi.n; j += 64) found = found || s.mv[j] == mv;
+        const bool legal = __ballot(found) != 0;
+        __syncthreads();
+        if (!legal) break;
+        game_push(d, g, b, mv, lane, s);
+        __threadfence_block();               // lane 0 wrote cur / ply / history ring: the next ply reads them
+        __syncthreads();
+    }
+    if (lane == 0) pushed[r] = i;
+}
+
 __global__ __launch_bounds__(64) void k_encode_cur(Dev d, void *planes)
 {
     __shared__ WaveLds s;

@@ -98,6 +98,7 @@ class LockstepEngine(object):
         self.pol_s1 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.pol_s2 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.val_s2 = torch.zeros((G,), dtype=torch.float32, device=self.dev)
+        self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2)
         self.use_graph = use_graph
         self._graph = None
         self._bind_stream()
@@ -109,6 +110,17 @@ class LockstepEngine(object):
     def close(self):
         self._graph = None
         self.ctx.close()
+
+    def shrink(self, n):
+        """Keep only slots [0, n) in the lockstep batch (finite runs: the batch thins out as games
+        end; the caller compacts the running games into the first slots with ``ctx.copy_game``).
+        Every later launch, tower batch and the re-captured hipGraph cover n games."""
+        if not 0 < n <= self._full[0].shape[0] or n % 4:
+            raise ValueError("shrink: n must be a multiple of 4 within the engine's capacity")
+        self.ctx.set_window(0, n)
+        self.G = n
+        self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2 = (t[:n] for t in self._full)
+        self._graph = None
 
     def _eval_into(self, planes, pol_out, val_out):
         fi = getattr(self.evaluator, "forward_into", None)
@@ -191,12 +203,14 @@ class LockstepEngine(object):
         """Replay per-slot move id sequences from the start position (tests / Game copies)."""
         self.reset()
         n = max((len(m) for m in move_lists), default=0)
-        for i in range(n):
-            mv = np.full(self.G, _lib.NO_MOVE, dtype=np.uint16)
-            for g, ml in enumerate(move_lists):
-                if i < len(ml):
-                    mv[g] = ml[i]
-            ok = self.ctx.push_moves(mv)
-            for g, ml in enumerate(move_lists):
-                if i < len(ml) and not ok[g]:
-                    raise ValueError("illegal move %d in sequence of slot %d" % (i, g))
+        if n == 0:
+            return
+        table = np.full((self.G, n), _lib.NO_MOVE, dtype=np.uint16)
+        counts = np.zeros(self.G, dtype=np.int32)
+        for g, ml in enumerate(move_lists):
+            table[g, :len(ml)] = ml
+            counts[g] = len(ml)
+        pushed = self.ctx.push_sequences(table, counts)
+        for g, ml in enumerate(move_lists):
+            if pushed[g] != len(ml):
+                raise ValueError("illegal move %d in sequence of slot %d" % (int(pushed[g]), g))

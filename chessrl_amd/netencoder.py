@@ -96,16 +96,16 @@ class DataGameSequence(object):
         ctx = self._context(n, dev.index or 0)
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctx.reset_games()
-        depth = np.array(depth)
-        table = np.full((n, int(depth.max()) + 1), _lib.NO_MOVE, dtype=np.uint16)
+        depth = np.array(depth, dtype=np.int32)
+        table = np.full((ctx.G, max(1, int(depth.max()))), _lib.NO_MOVE, dtype=np.uint16)
         for s in range(n):
             table[s, :depth[s]] = seqs[s][:depth[s]]
-        for ply in range(int(depth.max())):
-            mv = np.full(ctx.G, _lib.NO_MOVE, dtype=np.uint16)
-            mv[:n] = table[:, ply]
-            ok = ctx.push_moves(mv)
-            if not ok[:n][depth > ply].all():
-                raise ValueError("recorded game holds an illegal move at ply %d" % ply)
+        counts = np.zeros(ctx.G, dtype=np.int32)
+        counts[:n] = depth
+        pushed = ctx.push_sequences(table, counts)               # one launch replays every prefix
+        if not (pushed[:n] == depth).all():
+            bad = int(np.argmax(pushed[:n] != depth))
+            raise ValueError("recorded game holds an illegal move at ply %d" % int(pushed[bad]))
         planes = torch.empty((ctx.G, 8, 8, _lib.PLANES), dtype=torch.float16, device=dev)
         ctx.encode(planes.data_ptr())
         ctx.sync()

@@ -68,12 +68,14 @@ class SelfPlayRunner(object):
     """Lockstep self-play of ``n_parallel`` games on one GPU (one rank of ``world``)."""
 
     def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
-                 max_plies=2048, numpy_promotion="nep50", use_graph=True, total_games=None):
+                 max_plies=2048, numpy_promotion="nep50", use_graph=True, total_games=None,
+                 compact=True):
         self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
                                      numpy_promotion=numpy_promotion, use_graph=use_graph)
         self.G, self.sims, self.seed, self.noise = n_parallel, sims, seed, noise
         self.rank, self.world = rank, world
         self.total_games = total_games           # global cap on started games (None = endless)
+        self.compact = compact                   # finite runs: shrink the batch as games end
         self.max_plies = max_plies
         self.next_local = 0                      # k-th game of this rank has id rank + world*k
         self.game_id = np.full(n_parallel, -1, dtype=np.int64)
@@ -151,7 +153,37 @@ class SelfPlayRunner(object):
                 self.finished.append(GameRecord(self.game_id[g], moves[g, :plies[g]], int(res[g]),
                                                 bool(self.color[g])))
             self._start(done)
+            self._maybe_compact()
         return live
+
+    COMPACT_MIN = 64
+
+    def _maybe_compact(self):
+        """A finite run (``total_games``) stops refilling at some point and the batch thins out;
+        once at most half of the slots still play, the running games are moved into the first
+        slots (``crl_copy_game``: board, move stack and history) and the lockstep batch -- search
+        kernels, tower batch, hipGraph -- is halved.  What a game plays does not depend on its
+        slot (random streams are keyed by the game id), so the records are unchanged."""
+        if not self.compact or self.total_games is None or self.G <= self.COMPACT_MIN:
+            return
+        if self.rank + self.world * self.next_local < self.total_games:
+            return                                               # still refilling
+        act = np.nonzero(self.active())[0]
+        n_new = self.G
+        while n_new // 2 >= max(len(act), self.COMPACT_MIN) and (n_new // 2) % 4 == 0:
+            n_new //= 2
+        if n_new == self.G:
+            return
+        free = [s for s in range(n_new) if self.game_id[s] < 0]
+        for src in act[act >= n_new]:
+            dst = free.pop()
+            self.engine.ctx.copy_game(int(dst), int(src))
+            self.game_id[dst], self.color[dst], self.rngs[dst] = self.game_id[src], self.color[src], self.rngs[src]
+            self.game_id[src] = -1
+        self.engine.shrink(n_new)
+        self.G = n_new
+        self.game_id, self.color, self.rngs = self.game_id[:n_new], self.color[:n_new], self.rngs[:n_new]
+        log.debug("compacted the lockstep batch to %d slots (%d games running)", n_new, len(act))
 
     def play_move(self):
         """search_move + the two pushes for every running game (``sims`` lockstep steps)."""

@@ -94,6 +94,11 @@ int  crl_copy_game(crl_ctx *ctx, int dst, int src);
 int  crl_legal_moves(crl_ctx *ctx, uint16_t *moves /*G x 256*/, int32_t *counts /*G*/);
 /* Game.move (game.py:28-41): applied iff in the legal list; ok[g] = 1/0; CRL_NO_MOVE skips. */
 int  crl_push_moves(crl_ctx *ctx, const uint16_t *moves /*G*/, uint8_t *ok /*G*/);
+/* DatasetGame.loads / augment_game (dataset.py:21-57): every game replays its own recorded move
+ * list moves[g*stride .. g*stride+counts[g]) in ONE launch, each move through Game.move's legality
+ * test; pushed[g] = number of moves applied (stops at the first illegal move or CRL_NO_MOVE). */
+int  crl_push_sequences(crl_ctx *ctx, const uint16_t *moves /*G x stride*/, const int32_t *counts /*G*/,
+                        int stride, int32_t *pushed /*G*/);
 /* Game.get_result (game.py:92-109): 1 / -1 / 0, CRL_RESULT_NONE while running. */
 int  crl_results(crl_ctx *ctx, int8_t *result /*G*/);
 /* len(Game) and Game.get_history()['moves'] (game.py:59-66,111-112). */

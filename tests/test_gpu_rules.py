@@ -205,3 +205,45 @@ def test_perft_known_answers_through_the_cabi(ctx, fen):
         assert total == want, (fen, depth + 1, got)
         if children:
             frontier = np.concatenate(children)
+
+
+def test_push_sequences_replays_whole_move_lists_in_one_launch(ctx):
+    """crl_push_sequences == the same moves through crl_push_moves ply by ply; it stops at the first
+    illegal move (Game.move would refuse it) and reports how many were applied."""
+    from oracle.chess_oracle import move_to_uci, uci_to_move
+    rng = np.random.default_rng(77)
+    G = ctx.G
+    games = [OracleGame() for _ in range(G)]
+    lists = []
+    for i, g in enumerate(games):
+        want = i % 97                                     # lengths 0..96
+        ml = []
+        while len(ml) < want and g.get_result() is None:
+            lm = g.legal_move_ids()
+            m = lm[int(rng.integers(len(lm)))]
+            g.move(move_to_uci(m))
+            ml.append(m)
+        lists.append(ml)
+    L = max(len(m) for m in lists) + 3
+    table = np.full((G, L), 0xFFFF, dtype=np.uint16)
+    counts = np.zeros(G, dtype=np.int32)
+    for i, ml in enumerate(lists):
+        table[i, :len(ml)] = ml
+        counts[i] = len(ml)
+    # slot 5: an illegal move in the middle; slot 6: count larger than the list (NO_MOVE ends it)
+    table[5, 2] = uci_to_move("a1a8")
+    counts[6] = len(lists[6]) + 2
+    ctx.reset_games()
+    pushed = ctx.push_sequences(table, counts)
+    exp = counts.copy()
+    exp[5], exp[6] = 2, len(lists[6])
+    assert list(pushed) == list(exp)
+    pos = ctx.get_positions()
+    res = ctx.results()
+    _, plies, _ = ctx.records(with_moves=False)
+    for i, g in enumerate(games):
+        if i == 5:
+            assert plies[i] == 2
+            continue
+        assert plies[i] == len(g) and res[i] == _res(g), i
+        assert (pos[i] == oracle_row(g)).all(), i

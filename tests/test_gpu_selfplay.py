@@ -195,3 +195,28 @@ def test_game_agent_interactive_surface(agent_white):
         GameAgent(None)
     c.free()
     g.tearup()
+
+
+def test_compaction_of_a_thinning_batch_keeps_every_game_identical():
+    """A finite run stops refilling; the runner then halves the lockstep batch as games end
+    (copying the running games into the first slots).  Records must not depend on that, and three
+    of the games are checked against the oracle move for move."""
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=17, prior_shift=30)
+    kw = dict(n_parallel=256, sims=2, seed=9, noise=True, total_games=300, max_plies=2048)
+    a = SelfPlayRunner(net.to("cuda:0"), compact=True, **kw)
+    ra = {r.game_id: r for r in a.run()}
+    assert a.G == 64 and a.engine.G == 64                   # 256 -> 128 -> 64 slots
+    assert a.engine.ctx.counters()["sims"] == a.sims_run
+    a.close()
+    b = SelfPlayRunner(net.to("cuda:0"), compact=False, **kw)
+    rb = {r.game_id: r for r in b.run()}
+    assert b.G == 256
+    b.close()
+    assert sorted(ra) == sorted(rb) == list(range(300))
+    for k in ra:
+        assert ra[k] == rb[k], k
+    longest = sorted(ra, key=lambda k: -len(ra[k]))[:3]     # these lived through every compaction
+    for k in longest:
+        g = oracle_game(net, k, 9, 2, True)
+        assert ra[k].get_history()["moves"] == g.get_history()["moves"] and ra[k].result == g.get_result()
