@@ -32,6 +32,7 @@ SYMBOLS = [
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
+    "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
 
@@ -108,6 +109,8 @@ def lib():
     L.crl_counters.argtypes = [vp, vp]
     L.crl_trunk128_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
+    L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:
         if name not in ("crl_destroy", "crl_last_error"):
             getattr(L, name).restype = ctypes.c_int

@@ -5,6 +5,7 @@
 #include "tower.hpp"
 #include "tower_pipe.hpp"
 #include "tower_gen.hpp"
+#include "train_ops.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -569,6 +570,34 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
+}
+
+static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, int channels, bool forward)
+{
+    if (!src || !dst || n_boards < 1 || channels < 4 || channels % 4)
+        return fail(nullptr, CRL_ERR_ARG, "crl_im2col3x3_f32 / crl_col2im3x3_f32: bad argument");
+    const int c4 = channels / 4;
+    const long long total = (long long)n_boards * 64 * c4 * (forward ? 9 : 1);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (forward)
+        hipLaunchKernelGGL(crl_train::k_im2col3x3, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const float4 *)src, (float4 *)dst, total, c4);
+    else
+        hipLaunchKernelGGL(crl_train::k_col2im3x3, dim3(blocks), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const float4 *)src, (float4 *)dst, total, c4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_im2col3x3_f32(void *hip_stream, const void *dev_x_f32, void *dev_cols_f32, int n_boards, int channels)
+{
+    return train_op(hip_stream, dev_x_f32, dev_cols_f32, n_boards, channels, true);
+}
+
+int crl_col2im3x3_f32(void *hip_stream, const void *dev_gcols_f32, void *dev_gx_f32, int n_boards, int channels)
+{
+    return train_op(hip_stream, dev_gcols_f32, dev_gx_f32, n_boards, channels, false);
 }
 
 }  // extern "C"

@@ -32,6 +32,51 @@ ADAM_LR, ADAM_B1, ADAM_B2, ADAM_EPS = 0.002, 0.9, 0.999, 1e-7
 CCE_EPS = 1e-7            # keras.backend.epsilon()
 
 
+class _Im2Col3x3(torch.autograd.Function):
+    """Patch matrix of a 3x3 'same' convolution on NHWC boards and its adjoint: the two hand-written
+    HIP kernels of csrc/train_ops.hpp (one launch each, any batch size, deterministic backward)."""
+
+    @staticmethod
+    def _run(fn, src, dst, n_boards, channels):
+        import ctypes
+        from . import _lib
+        rc = fn(ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream),
+                ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), n_boards, channels)
+        if rc != 0:
+            raise _lib.HipLibraryError("train_ops kernel failed (%d)" % rc)
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        x = x.contiguous()
+        b, c = x.shape[0], x.shape[3]
+        ctx.shape = (b, c)
+        cols = torch.empty((b * 64, 9 * c), dtype=torch.float32, device=x.device)
+        _Im2Col3x3._run(_lib.lib().crl_im2col3x3_f32, x, cols, b, c)
+        return cols
+
+    @staticmethod
+    def backward(ctx, gcols):
+        from . import _lib
+        b, c = ctx.shape
+        gcols = gcols.contiguous()
+        gx = torch.empty((b, 8, 8, c), dtype=torch.float32, device=gcols.device)
+        _Im2Col3x3._run(_lib.lib().crl_col2im3x3_f32, gcols, gx, b, c)
+        return gx
+
+
+def im2col3x3(x):
+    """x [B,8,8,C] fp32 -> [B*64, 9*C], columns ordered (ky, kx, c).  CUDA tensors go through the HIP
+    kernels; the torch expression below is the same map for CPU tensors (unit tests of the module
+    on the host -- ``Trainer`` itself refuses to run without a GPU)."""
+    if x.is_cuda:
+        return _Im2Col3x3.apply(x)
+    b, c = x.shape[0], x.shape[3]
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    return torch.cat([xp[:, dy:dy + 8, dx:dx + 8, :] for dy in range(3) for dx in range(3)],
+                     dim=-1).reshape(b * 64, 9 * c)
+
+
 class TrainTower(nn.Module):
     """The tower with its BatchNorm layers unfolded, fp32, NHWC activations."""
 
@@ -118,17 +163,15 @@ class TrainTower(nn.Module):
     # Training batches are whole games, so every batch has a different number of positions.  MIOpen
     # looks up / compiles solvers per (batch, shape) for forward, backward-data and backward-weights
     # (measured: ~1.5 s for every new batch size), so the convolutions are written as what they are
-    # on an 8x8 board: a [B*64, 9*Cin] x [9*Cin, Cout] GEMM over the NHWC activations (im2col by nine
-    # shifted views of the zero-padded board), which rocBLAS/hipBLASLt run for any B; autograd gives
-    # the two backward GEMMs.  BatchNorm runs over the flattened [B*64, C] rows.
+    # on an 8x8 board: a [B*64, 9*Cin] x [9*Cin, Cout] GEMM over the NHWC activations (patch matrix and
+    # its adjoint: the HIP kernels of csrc/train_ops.hpp), which rocBLAS/hipBLASLt run for any B;
+    # autograd gives the two backward GEMMs.  BatchNorm runs over the flattened [B*64, C] rows.
     @staticmethod
     def _conv3x3(x, conv):
         """x [B,8,8,Cin] -> [B,8,8,Cout]; kernel OIHW viewed as [(ky,kx,c), o]."""
         b, cin = x.shape[0], x.shape[3]
-        xp = F.pad(x, (0, 0, 1, 1, 1, 1))
-        cols = torch.cat([xp[:, dy:dy + 8, dx:dx + 8, :] for dy in range(3) for dx in range(3)], dim=-1)
         wm = conv.weight.permute(2, 3, 1, 0).reshape(9 * cin, -1)
-        return torch.addmm(conv.bias, cols.reshape(b * 64, 9 * cin), wm).view(b, 8, 8, -1)
+        return torch.addmm(conv.bias, im2col3x3(x), wm).view(b, 8, 8, -1)
 
     @staticmethod
     def _conv1x1(x, conv):

