@@ -251,8 +251,11 @@ def main(argv=None):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
+        # self-test hooks for a 1-GPU box: CRL_DEVICE pins every rank to one device and
+        # CRL_DIST_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
+        local = int(os.environ.get("CRL_DEVICE", local))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("CRL_DIST_BACKEND", "nccl"))
     os.makedirs(args.model_dir, exist_ok=True)
     path = get_model_path(args.model_dir)
     weights = path if os.path.exists(path) else None

@@ -220,3 +220,33 @@ def test_compaction_of_a_thinning_batch_keeps_every_game_identical():
     for k in longest:
         g = oracle_game(net, k, 9, 2, True)
         assert ra[k].get_history()["moves"] == g.get_history()["moves"] and ra[k].result == g.get_result()
+
+
+def test_cli_two_ranks_play_train_and_share_the_weights(tmp_path):
+    """torchrun x 2 ranks (gloo, both on this GPU): games sharded by id, records gathered, rank 0
+    trains, the weights are broadcast, the second round plays with them on both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "models")
+    env = dict(os.environ, CRL_DIST_BACKEND="gloo", CRL_DEVICE="0")
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "chessrl_amd.selfplay", d,
+           "--games", "6", "--sims", "4", "--blocks", "1", "--filters", "64", "--rounds", "2", "--seed", "5"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = json.load(open(os.path.join(d, "gameplays.json")))
+    assert len(recs) == 12
+    # round 0 is played with the same seeded random-init weights as the single-process run of
+    # test_cli_plays_and_trains_rounds: sharding must not change those games
+    one = str(tmp_path / "single")
+    r1 = subprocess.run([sys.executable, "-m", "chessrl_amd.selfplay", one, "--games", "6", "--sims", "4",
+                         "--blocks", "1", "--filters", "64", "--seed", "5", "--no-train"],
+                        cwd=root, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    single = json.load(open(os.path.join(one, "gameplays.json")))
+    assert [g["moves"] for g in recs[:6]] == [g["moves"] for g in single]
+    assert len([l for l in open(os.path.join(d, "train_log.jsonl"))]) == 2
