@@ -227,7 +227,9 @@ def main():
         tree_ms = ph["select_expand"] + ph["reply"]
         tree = {"bound": "hbm", "kernel": "k_select_expand + k_reply (one simulation x %d games)" % G,
                 "achieved": tree_bytes * G / tree_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS,
+                # PMC passes of both kernels at 4096 games (profiles/r01/pmc_tree_kernels.md): bytes/step
+                "traffic": (2 * (27370e3 + 6435e3) + 102267e3 + 69172e3) if G == 4096 else None,
                 "launch_ms": tree_ms, "phase_ms": ph, "bytes_per_sim": tree_bytes,
                 "mean_depth": depth, "mean_branch": branch}
         out = {

@@ -1,0 +1,31 @@
+"""Scratch (GPU): run the search kernels for N lockstep steps with a constant evaluator (no tower
+kernels), for rocprofv3 --pmc passes over k_select_expand / k_reply.
+python tools/tree_once.py [games=4096] [steps=120]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from chessrl_amd.engine import LockstepEngine
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+g = torch.Generator(device="cuda:0").manual_seed(0)
+pol = torch.softmax(torch.randn((G, 1968), device="cuda:0", generator=g), -1)
+val = torch.tanh(torch.randn((G,), device="cuda:0", generator=g) * 0.3)
+
+
+class Const(object):
+    def __call__(self, planes):
+        return pol, val
+
+    def forward_into(self, planes, pol_out, val_out):      # the buffers already hold pol / val
+        pass
+
+
+eng = LockstepEngine(Const(), G, 800, use_graph=False)
+eng.pol_s1.copy_(pol); eng.pol_s2.copy_(pol); eng.val_s2.copy_(val)
+eng.reset()
+eng.search_begin()
+for _ in range(steps):
+    eng.step()
+torch.cuda.synchronize()
+c = eng.ctx.counters()
+print({k: int(v) for k, v in c.items()}, "depth", c["depth_sum"] / max(1, c["sims"]), "branch", c["branch_sum"] / max(1, c["nodes"]))
