@@ -160,19 +160,25 @@ class SelfPlayRunner(object):
 
     def _maybe_compact(self):
         """A finite run (``total_games``) stops refilling at some point and the batch thins out;
-        once at most half of the slots still play, the running games are moved into the first
+        whenever the running games fit a cheaper batch size, they are moved into the first
         slots (``crl_copy_game``: board, move stack and history) and the lockstep batch -- search
-        kernels, tower batch, hipGraph -- is halved.  What a game plays does not depend on its
+        kernels, tower batch, hipGraph -- shrinks to it.  What a game plays does not depend on its
         slot (random streams are keyed by the game id), so the records are unchanged."""
         if not self.compact or self.total_games is None or self.G <= self.COMPACT_MIN:
             return
         if self.rank + self.world * self.next_local < self.total_games:
             return                                               # still refilling
         act = np.nonzero(self.active())[0]
-        n_new = self.G
-        while n_new // 2 >= max(len(act), self.COMPACT_MIN) and (n_new // 2) % 4 == 0:
-            n_new //= 2
-        if n_new == self.G:
+        # batch sizes worth switching to: the trunk kernel runs 4 boards per workgroup on 256 CUs, so
+        # its cost steps at multiples of 1024 boards; below that the batch is halved
+        need = max(len(act), self.COMPACT_MIN)
+        if need > 1024:
+            n_new = (need + 1023) // 1024 * 1024
+        else:
+            n_new = self.COMPACT_MIN
+            while n_new < need:
+                n_new *= 2
+        if n_new >= self.G:
             return
         free = [s for s in range(n_new) if self.game_id[s] < 0]
         for src in act[act >= n_new]:
