@@ -148,3 +148,47 @@ def test_chess_model_saves_and_loads_keras_h5(tmp_path):
     m3 = ChessModel(blocks=2, filters=64, seed=9)
     m3.load_weights(p)
     assert torch.equal(m3(x)[0], p1)
+
+
+def test_container_roundtrip_property():
+    """hypothesis: random trees (nesting, names, dtypes, shapes incl. scalars and empty arrays,
+    byte-string and numeric attributes) survive write -> read unchanged."""
+    import tempfile
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    names = st.text(alphabet="abcdefghijklmnopqrstuvwxyz_0123456789:", min_size=1, max_size=24)
+    dtypes = st.sampled_from([np.float32, np.float64, np.int32, np.int64, np.uint8, np.float16])
+    arrays = dtypes.flatmap(lambda d: hnp.arrays(d, hnp.array_shapes(min_dims=0, max_dims=3, min_side=0, max_side=5),
+                                                 elements=st.integers(0, 100)))
+    attr_vals = st.one_of(st.binary(min_size=1, max_size=12).filter(lambda b: b"\0" not in b),
+                          arrays.filter(lambda a: a.size > 0),
+                          st.lists(st.binary(min_size=1, max_size=9).filter(lambda b: b"\0" not in b),
+                                   min_size=1, max_size=5).map(lambda l: np.array(l)))
+
+    def groups(depth):
+        leaf = st.dictionaries(names, arrays, max_size=4)
+        if depth == 0:
+            return leaf
+        return st.dictionaries(names, st.one_of(arrays, groups(depth - 1)), max_size=4)
+
+    def build(d, attrs):
+        g = h5lite.Group()
+        for k, v in d.items():
+            g[k] = build(v, {}) if isinstance(v, dict) else v
+        g.attrs.update(attrs)
+        return g
+
+    @settings(max_examples=40, deadline=None)
+    @given(groups(2), st.dictionaries(names, attr_vals, max_size=3))
+    def run(tree, attrs):
+        g = build(tree, attrs)
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "t.h5")
+            h5lite.write(p, g)
+            _same(g, h5lite.read(p))
+            if H5DUMP is not None and len(tree) % 3 == 0:          # the real library parses it too
+                r = subprocess.run([H5DUMP, p], capture_output=True, text=True, timeout=60)
+                assert r.returncode == 0 and "unable" not in r.stderr.lower(), r.stderr[-300:]
+
+    run()
