@@ -247,3 +247,13 @@ def test_push_sequences_replays_whole_move_lists_in_one_launch(ctx):
             continue
         assert plies[i] == len(g) and res[i] == _res(g), i
         assert (pos[i] == oracle_row(g)).all(), i
+
+
+def test_position_with_218_legal_moves_fills_the_move_arrays(ctx):
+    from tests.util import MAX_MOVES_FEN
+    g = OracleGame(board=board_from_fen(MAX_MOVES_FEN))
+    ctx.set_positions(np.stack([board_to_array(board_from_fen(MAX_MOVES_FEN))] * 3))
+    moves, counts = ctx.legal_moves()
+    assert counts[0] == counts[2] == 218
+    assert list(moves[2, :218]) == g.legal_move_ids()
+    assert ctx.results()[0] == 2

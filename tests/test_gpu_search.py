@@ -161,6 +161,30 @@ def test_search_across_the_fifty_move_claim_and_mates():
     eng.close()
 
 
+def test_search_from_the_218_move_position_fills_the_edge_pool():
+    """A root with 218 children (the worst case the edge pool ECAP = N x 218 is sized for): 240
+    simulations expand all of them, apply the priors and descend again; children hold up to 80+
+    replies' worth of edges each."""
+    from chessrl_amd.engine import LockstepEngine
+    from oracle.chess_oracle import board_from_fen, board_to_array
+    from tests.util import MAX_MOVES_FEN
+    sims = 240
+    g = OracleGame(board=board_from_fen(MAX_MOVES_FEN))
+    net = FakeNet(seed=3, prior_shift=30)
+    eng = LockstepEngine(net.to("cuda:0"), n_games=4, max_sims=sims)
+    eng.ctx.set_positions(np.stack([board_to_array(board_from_fen(MAX_MOVES_FEN))] * 4))
+    eng.search(sims)
+    rc = eng.root_children()
+    r = mcts_oracle.search(g, mcts_oracle.OracleAgent(net), sims, noise=False)
+    for i in (0, 3):
+        assert rc["nchild"][i] == 218 == len(r.visits)
+        assert list(rc["visits"][i, :218]) == r.visits
+        assert np.array_equal(rc["values"][i, :218].view(np.uint64),
+                              np.array(r.values, dtype=np.float64).view(np.uint64))
+        assert np.array_equal(rc["priors"][i, :218], np.array(r.priors, dtype=np.float32))
+    eng.close()
+
+
 def test_search_then_advance_matches_oracle_game():
     """Three full moves of selfplay.play_game (search -> choose -> two pushes), noise off."""
     from chessrl_amd.engine import LockstepEngine, compute_policy

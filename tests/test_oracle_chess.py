@@ -95,3 +95,12 @@ def test_results():
         for u in ["g1f3", "g8f6", "f3g1", "f6g8"]:
             g.move(u)
     assert g.repetitions() == 5 and g.get_result() == 0                 # fivefold, not threefold
+
+
+def test_position_with_the_maximum_number_of_legal_moves():
+    """218 legal moves (the published maximum): the size every move / edge array is built for."""
+    from tests.util import MAX_MOVES_FEN
+    g = OracleGame(board=board_from_fen(MAX_MOVES_FEN))
+    lm = g.get_legal_moves()
+    assert len(lm) == 218 and len(set(lm)) == 218
+    assert g.get_result() is None

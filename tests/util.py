@@ -13,6 +13,9 @@ PERFT_FENS = {
     "promo": "n1n5/PPPk4/8/8/8/8/4Kppp/5N1N b - - 0 1",
     "dblcheck": "4k3/8/8/8/8/5n2/4r3/4K3 w - - 0 1",
 }
+# the known position with the most legal moves of any reachable chess position (218): the capacity
+# of every per-node move / edge array (CRL_MAX_MOVES)
+MAX_MOVES_FEN = "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1"
 
 
 def array_to_board(a):
