@@ -68,3 +68,31 @@ def test_trained_weights_broadcast_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok and keys for _, ok, keys in got)
+
+
+def _empty_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.game import uci_to_move
+    mine = [] if rank == 0 else [records.GameRecord(1, [uci_to_move("d2d4")] * 5, 0, False),
+                                 records.GameRecord(3, [], None, True)]      # an empty, unfinished game
+    allr = records.gather_records(mine, max_plies=16)
+    q.put((rank, [(r.game_id, len(r.moves), r.result) for r in allr]))
+    dist.destroy_process_group()
+
+
+def test_gather_records_with_an_empty_rank_and_an_empty_game():
+    """Ragged input: one rank finished nothing, another holds a zero-ply game with result None."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_empty_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [(1, 5, 0), (3, 0, None)]
