@@ -288,6 +288,11 @@ class ChessModel(object):
         self.load_dict(_read_weights(weights_path))
         self._trainer = None                     # optimizer state belongs to the old weights
 
+    def reset_optimizer(self):
+        """Forget the Adam moments and step count (a fresh ``compile`` in the reference: every
+        ``train_model_job`` of selfplay.py:98-108 runs in a new process with a new optimizer)."""
+        self._trainer = None
+
     def train_generator(self, generator, epochs=1, logdir=None, val_gen=None, verbose=0):
         """model.py:83-99 (``fit_generator`` over a ``DataGameSequence``).  Where the reference
         attaches a TensorBoard callback, ``logdir`` receives one JSON line per epoch in

@@ -58,7 +58,7 @@ class DataGameSequence(object):
         self._ctx = None
 
     def __len__(self):
-        return int(len(self.dataset) / self.batch_size)
+        return int(len(self.dataset) / self.batch_size) if self.batch_size else 0
 
     def _context(self, n, device=0):
         if self._ctx is None or self._ctx.G < n or self._ctx.device != device:

@@ -224,6 +224,7 @@ def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=
     if len(data_train) == 0:
         return None
     gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
+    model.reset_optimizer()             # the reference trains each round in a fresh process
     history = model.train_generator(gen, epochs=epochs, logdir=model_dir)
     model.save_weights(model_path)
     return history
