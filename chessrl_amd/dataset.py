@@ -34,7 +34,7 @@ class DatasetGame(object):
 
     def loads(self, string, slot_free=False):
         """dataset.py:50-57.  ``slot_free=True`` keeps the games as ``GameRecord``s (no device
-        slot per game: training sets larger than the 512-slot ``Game`` arena); the moves are then
+        slot per game: training sets larger than the 4096-slot ``Game`` arena); the moves are then
         replayed -- and checked -- on the device when a batch is built."""
         if slot_free:
             from . import records

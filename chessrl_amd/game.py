@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 
-ARENA_SLOTS = 512
+ARENA_SLOTS = 4096
 ARENA_MAX_PLIES = 4096
 _FILES = "abcdefgh"
 _PROMO = " pnbrqk"
