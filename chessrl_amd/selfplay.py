@@ -68,7 +68,7 @@ class SelfPlayRunner(object):
     """Lockstep self-play of ``n_parallel`` games on one GPU (one rank of ``world``)."""
 
     def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
-                 max_plies=2048, numpy_promotion="nep50", use_graph=True, total_games=None,
+                 max_plies=4096, numpy_promotion="nep50", use_graph=True, total_games=None,
                  compact=True):
         self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
                                      numpy_promotion=numpy_promotion, use_graph=use_graph)
