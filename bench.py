@@ -220,16 +220,18 @@ def main():
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}
         # ---- hand-written HIP search kernels (HBM-bound): select+expand and reply -----------
         # algorithmic bytes per simulation, SURVEY.md section 8d with the measured d and b;
-        # planes and policy vectors ARE materialised in this build (+2*16 KiB written by the
-        # encoders, read by the tower; +2*b*4 B gathered from the f32 policies)
-        tree_bytes = 2400.0 + 20.0 * depth * branch + 2 * 16384.0
+        # with the fused trunk the encoders hand over 1-KiB plane bitboards (expanded on chip); any
+        # other evaluator gets 16-KiB fp16 planes.  Policy vectors are materialised (+2*b*4 B gathered)
+        plane_bytes = 1024.0 if eng.bitplanes else 16384.0      # per evaluated position (S1 and S2)
+        tree_bytes = 2400.0 + 20.0 * depth * branch + 2 * plane_bytes
         ph = profile_phases(run, 16)
         tree_ms = ph["select_expand"] + ph["reply"]
         tree = {"bound": "hbm", "kernel": "k_select_expand + k_reply (one simulation x %d games)" % G,
                 "achieved": tree_bytes * G / tree_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS,
                 # PMC passes of both kernels at 4096 games (profiles/r01/pmc_tree_kernels.md): bytes/step
-                "traffic": (2 * (27370e3 + 6435e3) + 102267e3 + 69172e3) if G == 4096 else None,
+                "traffic": ((2 * (16054e3 + 6415e3) + 42729e3 + 7731e3) if eng.bitplanes else
+                            (2 * (27370e3 + 6435e3) + 102267e3 + 69172e3)) if G == 4096 else None,
                 "launch_ms": tree_ms, "phase_ms": ph, "bytes_per_sim": tree_bytes,
                 "mean_depth": depth, "mean_branch": branch}
         out = {

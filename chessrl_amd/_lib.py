@@ -27,11 +27,12 @@ FLAG_NUMPY_LEGACY = 1
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
-    "crl_max_sims", "crl_set_window", "crl_copy_game", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
+    "crl_max_sims", "crl_set_window", "crl_set_plane_format", "crl_copy_game", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_push_sequences", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
+    "crl_trunk_forward_bitplanes",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -109,6 +110,8 @@ def lib():
     L.crl_counters.argtypes = [vp, vp]
     L.crl_trunk128_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:
@@ -168,6 +171,10 @@ class Context(object):
         """Later calls act on slots [first, first+count); arrays become `count` rows."""
         self._ck(self._L.crl_set_window(self._h, first, count), "crl_set_window")
         self.G = count
+
+    def set_plane_format(self, bits):
+        """Encoders write fp16 NHWC planes (False, default) or 128 plane bitboards per position (True)."""
+        self._ck(self._L.crl_set_plane_format(self._h, 1 if bits else 0), "crl_set_plane_format")
 
     def copy_game(self, dst, src):
         self._ck(self._L.crl_copy_game(self._h, dst, src), "crl_copy_game")

@@ -161,6 +161,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     d.MAXPLY = max_plies;
     d.flags = flags;
     d.g0 = 0;
+    d.plane_fmt = CRL_PLANES_F16;
     ctx->W = max_games;
     const size_t G = d.G, GN = G * d.N, GE = G * (size_t)d.ECAP;
     bool ok = true;
@@ -237,6 +238,14 @@ int crl_set_window(crl_ctx *ctx, int first, int count)
         return fail(ctx, CRL_ERR_ARG, "crl_set_window: bad slot range");
     ctx->d.g0 = first;
     ctx->W = count;
+    return CRL_OK;
+}
+
+int crl_set_plane_format(crl_ctx *ctx, int format)
+{
+    if (!ctx || (format != CRL_PLANES_F16 && format != CRL_PLANES_BITS))
+        return fail(ctx, CRL_ERR_ARG, "crl_set_plane_format: bad argument");
+    ctx->d.plane_fmt = format;
     return CRL_OK;
 }
 
@@ -494,10 +503,10 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
                              n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
-int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
-                      const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
-                      int n_boards, int n_blocks, const void *dev_head_w_f32,
-                      const void *dev_head_b_f32, void *dev_head_out_f32)
+static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, bool bits,
+                         const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                         int n_boards, int n_blocks, const void *dev_head_w_f32,
+                         const void *dev_head_b_f32, void *dev_head_out_f32)
 {
     if (filters != 64 && filters != 128 && filters != 256)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 64, 128 and 256 filters");
@@ -508,7 +517,7 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
-    kern_t kern = crl_tower::k_trunk128_pipe<0>;       // production, 128 filters
+    kern_t kern = bits ? crl_tower::k_trunk128_pipe<0, 1> : crl_tower::k_trunk128_pipe<0, 0>;   // production, 128 filters
     int lds_bytes = crl_tower::P2_LDS_BYTES;
     int boards_per_wg = crl_tower::BOARDS_PER_WG;
     // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
@@ -516,7 +525,7 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
     const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && !getenv("CRL_TRUNK_NO_SMALL");
 #define CRL_GEN(F_, NB_)                                                                        \
     do {                                                                                         \
-        kern = crl_tower::k_trunk_gen<F_, NB_>;                                                  \
+        kern = bits ? crl_tower::k_trunk_gen<F_, NB_, 1> : crl_tower::k_trunk_gen<F_, NB_, 0>;   \
         lds_bytes = crl_tower::Geo<F_, NB_>::LDS_BYTES;                                          \
         boards_per_wg = NB_;                                                                     \
     } while (0)
@@ -526,7 +535,7 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
         if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4);
     } else if (small) {
         CRL_GEN(128, 2);
-    } else if (const char *ev = getenv("CRL_TRUNK_VARIANT")) {
+    } else if (const char *ev = bits ? nullptr : getenv("CRL_TRUNK_VARIANT")) {
         // tuning / timing-only builds of the 128-filter kernel (tools/trunk_bench.py; the ladder in
         // profiles/r01/pmc_trunk_kernel.md).  Unset or 0 = production.
         const int first = crl_tower::LDS_BYTES;        // LDS size of the first-build kernels
@@ -570,6 +579,24 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
+}
+
+int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
+                      const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                      int n_boards, int n_blocks, const void *dev_head_w_f32,
+                      const void *dev_head_b_f32, void *dev_head_out_f32)
+{
+    return trunk_forward(hip_stream, filters, dev_planes_f16, false, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
+}
+
+int crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_bitplanes_u64,
+                                const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                                int n_boards, int n_blocks, const void *dev_head_w_f32,
+                                const void *dev_head_b_f32, void *dev_head_out_f32)
+{
+    return trunk_forward(hip_stream, filters, dev_bitplanes_u64, true, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
 static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, int channels, bool forward)

@@ -139,6 +139,15 @@ __device__ inline void encode_position(const Dev &d, int g, const Board &b, int 
         s.pl[c] = v;
     }
     __syncthreads();
+    if (d.plane_fmt) {
+        // compact form for the fused trunk (crl_trunk_forward_bitplanes): the 128 plane bitboards,
+        // 1 KiB per position instead of 16 KiB; the trunk kernel expands them into LDS itself
+        u64 *bits = (u64 *)planes_out + (size_t)row * PLANES;
+        bits[lane] = s.pl[lane];
+        bits[lane + 64] = s.pl[lane + 64];
+        __syncthreads();
+        return;
+    }
     const int cg = lane & 15;
     u64 p8[8];
 #pragma unroll

@@ -57,6 +57,7 @@ struct Dev {
     int G, N, ECAP, MAXPLY;
     int g0;                            // first slot of the active window (I/O rows are window-relative)
     u32 flags;
+    int plane_fmt;                     // 0: encoders write fp16 NHWC planes, 1: 128 bit planes per position
     // games
     Board *cur;
     int32_t *ply;

@@ -80,7 +80,7 @@ __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, 
 //   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
-template <int F, int NB>
+template <int F, int NB, int BITS = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -109,14 +109,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
     stage_wtile_gen<G>(wts, lds, 2, tid);
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
+        if constexpr (BITS) {
+            expand_bitplanes<G::NB, G::AROW, G::ABOARD>(planes, lds, wg_board0, tid);
+        } else {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
 #pragma unroll
-        for (int i = 0; i < G::NB * 2; i++) {
-            const int c16 = i * 512 + tid;
-            const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
-            u32x4 v = src[c16];
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
-                lds + b * G::ABOARD + p * G::AROW + (c << 4)) = v;
+            for (int i = 0; i < G::NB * 2; i++) {
+                const int c16 = i * 512 + tid;
+                const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
+                u32x4 v = src[c16];
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
+                    lds + b * G::ABOARD + p * G::AROW + (c << 4)) = v;
+            }
         }
         for (int i = tid; i < G::ZERO_BYTES / 16; i += 512)
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =

@@ -55,6 +55,30 @@ __device__ __forceinline__ half8 lds_read16_asm(int addr)
     return v;
 }
 
+// Input given as 128 plane bitboards per board (u64 [n_boards][128]; bit sq of plane c = channel c
+// on square sq -- what the encoder builds before it would expand them, csrc/search.hpp): expand them
+// into the padded fp16 activation rows of the NB resident boards.  One item = (board, position,
+// 16 channels) = two 16-byte LDS stores; NB items per thread of a 512-thread workgroup.
+template <int NB, int AROW, int ABOARD>
+__device__ inline void expand_bitplanes(const unsigned char *planes, lds_byte *lds, size_t wg_board0, int tid)
+{
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(planes) + wg_board0 * 128;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int item = k * 512 + tid;
+        const int b = item >> 9, p = (item >> 3) & 63, c = item & 7;
+        const int sq = p ^ 56;                          // row 0 of the planes is rank 8
+        const unsigned long long *m = src + b * 128 + c * 16;
+        unsigned int w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            w[q] = (((m[2 * q] >> sq) & 1) ? 0x3C00u : 0u) | (((m[2 * q + 1] >> sq) & 1) ? 0x3C000000u : 0u);
+        lds_byte *dst = lds + b * ABOARD + p * AROW + c * 32;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst + 16) = u32x4{w[4], w[5], w[6], w[7]};
+    }
+}
+
 constexpr int P2_AROW = ROW_BYTES + 16;                             // padded activation row
 constexpr int P2_ABOARD = 64 * P2_AROW;
 constexpr int P2_ZERO_OFF = BOARDS_PER_WG * P2_ABOARD;              // 16 zero rows
@@ -85,7 +109,8 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
 // DIAG = 0: production.  Timing-only builds (WRONG results): bit 0 = no weight staging in the loop,
 // bit 1 = no per-tile barrier.  Bit 2 (correct results) = staggered staging: waves 0-3 stage at the
 // mid-step barrier, waves 4-7 half a K-step later (measured 2 % slower than staging together).
-template <int DIAG = 0>
+// BITS = 1: `planes` holds 128 plane bitboards per board (expand_bitplanes) instead of fp16 planes.
+template <int DIAG = 0, int BITS = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *__restrict__ planes,
                                                            const unsigned char *__restrict__ wts,
                                                            const float *__restrict__ bias,
@@ -111,14 +136,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
 
     // ---- planes -> padded LDS image; zero rows; biases -------------------------------------------------
     {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
+        if constexpr (BITS) {
+            expand_bitplanes<BOARDS_PER_WG, P2_AROW, P2_ABOARD>(planes, lds, wg_board0, tid);
+        } else {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int c16 = i * 512 + tid;              // 16-B chunk of the 64-KiB input block
-            const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
-            u32x4 v = src[c16];
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
-                lds + b * P2_ABOARD + p * P2_AROW + (c << 4)) = v;
+            for (int i = 0; i < 8; i++) {
+                const int c16 = i * 512 + tid;          // 16-B chunk of the 64-KiB input block
+                const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
+                u32x4 v = src[c16];
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
+                    lds + b * P2_ABOARD + p * P2_AROW + (c << 4)) = v;
+            }
         }
         if (tid < P2_ZERO_BYTES / 16)
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + P2_ZERO_OFF + tid * 16) =

@@ -77,11 +77,12 @@ def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None):
 class LockstepEngine(object):
     """G games x one search tree each on one GPU.
 
-    evaluator(planes[G,8,8,128] fp16 cuda) -> (policy[G,1968] f32, value[G] f32) cuda tensors.
+    evaluator(planes[G,8,8,128] fp16 cuda) -> (policy[G,1968] f32, value[G] f32) cuda tensors; an
+    evaluator with ``accepts_bitplanes`` is given int64 [G,128] plane bitboards instead.
     """
 
     def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
-                 numpy_promotion="nep50", use_graph=True):
+                 numpy_promotion="nep50", use_graph=True, bitplanes=None):
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
         if numpy_promotion not in ("nep50", "legacy"):
@@ -93,8 +94,19 @@ class LockstepEngine(object):
                                 numpy_legacy=(numpy_promotion == "legacy"))
         self.evaluator = evaluator
         G = n_games
-        self.planes_s1 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
-        self.planes_s2 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
+        # An evaluator that runs the fused HIP trunk takes the encoder's compact form -- 128 plane
+        # bitboards (1 KiB) per position -- and expands it on chip: the 16-KiB fp16 planes are then
+        # never written to HBM.  Any other evaluator gets the fp16 NHWC planes.
+        if bitplanes is None:
+            bitplanes = bool(getattr(evaluator, "accepts_bitplanes", False))
+        self.bitplanes = bitplanes
+        if bitplanes:
+            self.ctx.set_plane_format(True)
+            self.planes_s1 = torch.zeros((G, _lib.PLANES), dtype=torch.int64, device=self.dev)
+            self.planes_s2 = torch.zeros((G, _lib.PLANES), dtype=torch.int64, device=self.dev)
+        else:
+            self.planes_s1 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
+            self.planes_s2 = torch.zeros((G, 8, 8, _lib.PLANES), dtype=torch.float16, device=self.dev)
         self.pol_s1 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.pol_s2 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.val_s2 = torch.zeros((G,), dtype=torch.float32, device=self.dev)

@@ -229,18 +229,28 @@ class ChessModel(object):
             self._wtiles, self._wbias, self._head_w, self._head_b = (
                 t.to(self.device).contiguous() for t in new)
             self._pad_in = None
+            self._pad_bits = None
         else:                                                  # in place: captured graphs stay valid
             for dst, src in zip((self._wtiles, self._wbias, self._head_w, self._head_b), new):
                 dst.copy_(src)
 
     def _run_fused(self, planes, want_trunk=False):
-        """One launch of the fused trunk kernel.  Returns (trunk fp32 [B,8,8,F] or None,
-        head activations fp32 [B,192] = ReLU(1x1 head convs): 128 policy + 64 value)."""
+        """One launch of the fused trunk kernel.  ``planes``: fp16 NHWC [B,8,8,128], or int64
+        [B,128] plane bitboards (the encoder's compact form; the kernel expands them on chip).
+        Returns (trunk fp32 [B,8,8,F] or None, head activations fp32 [B,192] = ReLU(1x1 head
+        convs): 128 policy + 64 value)."""
         import ctypes
         from . import _lib
         b = planes.shape[0]
         bp = (b + 3) // 4 * 4
-        if bp != b or not planes.is_contiguous() or planes.dtype != torch.float16:
+        bits = planes.dtype == torch.int64       # 128 plane bitboards per board (CRL_PLANES_BITS)
+        if bits:
+            if bp != b or not planes.is_contiguous():
+                if self._pad_bits is None or self._pad_bits.shape[0] != bp:
+                    self._pad_bits = torch.zeros((bp, PAD_PLANES), dtype=torch.int64, device=self.device)
+                self._pad_bits[:b].copy_(planes)
+                planes = self._pad_bits
+        elif bp != b or not planes.is_contiguous() or planes.dtype != torch.float16:
             if self._pad_in is None or self._pad_in.shape[0] != bp:
                 self._pad_in = torch.zeros((bp, 8, 8, PAD_PLANES), dtype=torch.float16, device=self.device)
             self._pad_in[:b].copy_(planes)
@@ -248,7 +258,8 @@ class ChessModel(object):
         trunk = (torch.empty((bp, 8, 8, self.filters), dtype=torch.float32, device=self.device)
                  if want_trunk else None)
         heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
-        rc = _lib.lib().crl_trunk_forward(
+        fn = _lib.lib().crl_trunk_forward_bitplanes if bits else _lib.lib().crl_trunk_forward
+        rc = fn(
             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters,
             ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(self._wtiles.data_ptr()),
             ctypes.c_void_p(self._wbias.data_ptr()),
@@ -325,10 +336,17 @@ class ChessModel(object):
         else:
             np.savez(weights_path, **self.weights)
 
+    @property
+    def accepts_bitplanes(self):
+        """The fused HIP trunk expands the encoder's 128 plane bitboards itself (engine.py)."""
+        return self.fused
+
     @torch.no_grad()
     def __call__(self, planes):
         if self.fused:
             return self._forward_fused(planes)
+        if planes.dtype == torch.int64:
+            raise ValueError("plane bitboards are only understood by the fused HIP trunk")
         x = planes.to(self.dtype).permute(0, 3, 1, 2)         # NHWC memory viewed as NCHW
         return self.net(x)
 

@@ -73,6 +73,15 @@ const char *crl_last_error(crl_ctx *ctx);    /* ctx may be NULL for crl_create f
 /* Restrict every later call to slots [first, first+count): host arrays and dev_ rows are then
  * indexed relative to `first` and sized by `count` instead of G (default window = all G). */
 int  crl_set_window(crl_ctx *ctx, int first, int count);
+/* What the encoding entry points (crl_encode, crl_search_begin, crl_sim_select_expand,
+ * crl_sim_reply: netencoder.get_game_state, netencoder.py:72-91) write per position:
+ * CRL_PLANES_F16 (default) = the fp16 NHWC planes [8][8][128] (16 KiB);
+ * CRL_PLANES_BITS = the same information as 128 plane bitboards, uint64 [128] (1 KiB; bit s of
+ * plane c = channel c on square s, a1 = 0): the input of crl_trunk_forward_bitplanes, which expands
+ * it on chip, so that the planes never exist in HBM. */
+#define CRL_PLANES_F16  0
+#define CRL_PLANES_BITS 1
+int  crl_set_plane_format(crl_ctx *ctx, int format);
 int  crl_max_games(crl_ctx *ctx);
 int  crl_max_sims(crl_ctx *ctx);
 
@@ -174,6 +183,13 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
                        const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                        int n_boards, int n_blocks, const void *dev_head_w_f32,
                        const void *dev_head_b_f32, void *dev_head_out_f32);
+
+/* crl_trunk_forward with the input given as plane bitboards (CRL_PLANES_BITS), uint64
+ * [n_boards][128]; everything else as above. */
+int  crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_bitplanes_u64,
+                                 const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                                 int n_boards, int n_blocks, const void *dev_head_w_f32,
+                                 const void *dev_head_b_f32, void *dev_head_out_f32);
 
 /* ---- training step (model.py:83-99 fit_generator) --------------------
  * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'

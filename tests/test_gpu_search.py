@@ -307,6 +307,69 @@ def test_fused_trunk_matches_pytorch_trunk_activations(filters, n_boards):
         assert (heads - heads_big).abs().max().item() <= 1e-5 * max(1.0, heads.abs().max().item())
 
 
+def _bits_from_planes(planes):
+    """fp16/0-1 planes [B,8,8,128] -> int64 [B,128] plane bitboards (bit sq, spatial index sq ^ 56)."""
+    b = planes.shape[0]
+    flat = planes.reshape(b, 64, 128).to(torch.int64)                 # [B, p, c]
+    sq = torch.arange(64, device=planes.device) ^ 56                  # square of spatial index p
+    w = (torch.ones(64, dtype=torch.int64, device=planes.device) << sq)
+    return (flat * w.view(1, 64, 1)).sum(dim=1)                       # bit 63 wraps to the sign bit
+
+
+def test_encoder_bitplane_format_holds_the_same_planes():
+    """CRL_PLANES_BITS vs CRL_PLANES_F16 from the same positions (with history)."""
+    from chessrl_amd.engine import LockstepEngine
+    games = random_prefix_games(48, 90, seed=17)
+    a = LockstepEngine(lambda p: None, n_games=48, max_sims=4, use_graph=False)
+    b = LockstepEngine(lambda p: None, n_games=48, max_sims=4, use_graph=False, bitplanes=True)
+    for e in (a, b):
+        e.load_moves([move_ids(g) for g in games])
+        e.ctx.encode(e.planes_s1.data_ptr())
+        e.ctx.sync()
+    assert b.planes_s1.dtype == torch.int64 and b.planes_s1.shape == (48, 128)
+    assert torch.equal(_bits_from_planes(a.planes_s1), b.planes_s1)
+    assert (b.planes_s1[:, 127] == 0).all()
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("n_boards", [30, 516])
+@pytest.mark.parametrize("filters", [64, 128, 256])
+def test_fused_trunk_from_bitplanes_is_bit_identical(filters, n_boards):
+    """crl_trunk_forward_bitplanes expands the bitboards on chip: same bits out as from fp16 planes."""
+    from chessrl_amd.model import ChessModel
+    model = ChessModel(weights=tower_oracle.init_weights(3, filters, seed=12, randomize_bn=True))
+    rng = np.random.default_rng(filters + n_boards)
+    planes = torch.zeros((n_boards, 8, 8, 128), dtype=torch.float16, device="cuda:0")
+    planes[..., :127] = torch.from_numpy((rng.random((n_boards, 8, 8, 127)) < 0.2).astype(np.float16)).cuda()
+    bits = _bits_from_planes(planes)
+    t0, h0 = model._run_fused(planes, want_trunk=True)
+    t1, h1 = model._run_fused(bits, want_trunk=True)
+    assert torch.equal(t0, t1) and torch.equal(h0, h1)
+    (p0, v0), (p1, v1) = model(planes), model(bits)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+def test_search_with_the_real_tower_is_identical_in_both_plane_formats():
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    model = ChessModel(blocks=2, filters=64, seed=1)
+    games = random_prefix_games(16, 50, seed=23)
+    out = []
+    for bits in (False, True):
+        eng = LockstepEngine(model, n_games=16, max_sims=40, bitplanes=bits)
+        assert eng.bitplanes == bits
+        eng.load_moves([move_ids(g) for g in games])
+        eng.search(40)
+        out.append(eng.root_children())
+        eng.close()
+    a, b = out
+    assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
+    assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+    assert np.array_equal(a["priors"], b["priors"]) and np.array_equal(a["replies"], b["replies"])
+    assert LockstepEngine(model, n_games=4, max_sims=2).bitplanes        # the default for a fused model
+
+
 def test_search_matches_committed_golden_vectors(golden_dir):
     """HIP search vs tests/golden/mcts_cases.json: the outputs of the reference's own mctree.py
     (oracle/make_golden.py), both numpy promotion modes, incl. a case where the modes differ."""

@@ -1,6 +1,6 @@
 """Scratch (GPU): run the search kernels for N lockstep steps with a constant evaluator (no tower
 kernels), for rocprofv3 --pmc passes over k_select_expand / k_reply.
-python tools/tree_once.py [games=4096] [steps=120]"""
+python tools/tree_once.py [games=4096] [steps=120] [bitplanes=1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +13,8 @@ val = torch.tanh(torch.randn((G,), device="cuda:0", generator=g) * 0.3)
 
 
 class Const(object):
+    accepts_bitplanes = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0    # production: 1-KiB bitboards
+
     def __call__(self, planes):
         return pol, val
 
