@@ -196,8 +196,10 @@ def main():
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
             k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (
                 # the dispatch rule of crl_trunk_forward (csrc/api.hip)
-                ("k_trunk_gen<%d, %d>" % (F, (1 if F == 256 else 2)) if G <= 128 * (2 if F == 256 else 4)
-                 else "k_trunk128_pipe<0>" if F == 128 else "k_trunk_gen<%d, %d>" % (F, 2 if F == 256 else 4)),
+                ("k_trunk_gen<%d, %d, %d>" % (F, (1 if F == 256 else 2), eng.bitplanes)
+                 if G <= 128 * (2 if F == 256 else 4)
+                 else "k_trunk128_pipe<0, %d>" % eng.bitplanes if F == 128
+                 else "k_trunk_gen<%d, %d, %d>" % (F, 2 if F == 256 else 4, eng.bitplanes)),
                 B, G)
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
