@@ -154,7 +154,7 @@ def test_container_roundtrip_property():
     """hypothesis: random trees (nesting, names, dtypes, shapes incl. scalars and empty arrays,
     byte-string and numeric attributes) survive write -> read unchanged."""
     import tempfile
-    from hypothesis import given, settings, strategies as st
+    from hypothesis import HealthCheck, given, settings, strategies as st
     from hypothesis.extra import numpy as hnp
 
     names = st.text(alphabet="abcdefghijklmnopqrstuvwxyz_0123456789:", min_size=1, max_size=24)
@@ -179,7 +179,8 @@ def test_container_roundtrip_property():
         g.attrs.update(attrs)
         return g
 
-    @settings(max_examples=40, deadline=None)
+    @settings(max_examples=40, deadline=None, derandomize=True, database=None,
+              suppress_health_check=list(HealthCheck))
     @given(groups(2), st.dictionaries(names, attr_vals, max_size=3))
     def run(tree, attrs):
         g = build(tree, attrs)
