@@ -12,9 +12,11 @@ One *step* = one ``explore_tree`` for every game:
 
 All four are enqueued on one HIP stream with no host synchronisation and are
 captured once into a hipGraph (torch.cuda.CUDAGraph) that is replayed S times
-per move.  Tensors never leave HBM: the encoder kernels write the tower's fp16
-NHWC input in place and the search kernels read the tower's fp32 outputs in
-place (``torch.Tensor.data_ptr()`` across the C-ABI).
+per move.  Tensors never leave HBM: the encoder kernels write the tower's input
+in place -- 128 plane bitboards per position for the fused HIP trunk, which
+expands them on chip, or fp16 NHWC planes for any other evaluator -- and the
+search kernels read the tower's fp32 outputs in place
+(``torch.Tensor.data_ptr()`` across the C-ABI).
 
 Sequential ``threads=1`` semantics of the reference (the only deterministic
 mode): per game, simulations are strictly ordered.
