@@ -65,6 +65,31 @@ class _Im2Col3x3(torch.autograd.Function):
         return gx
 
 
+class _PatchGemm(torch.autograd.Function):
+    """out = cols @ wm + bias with a split-K weight gradient.
+
+    The weight gradient cols^T @ gout has K = B*64 (~24 000 for one game) against a 1152 x 128 output:
+    as ONE GEMM rocBLAS runs it at 42 TFLOP/s (too few output tiles for 256 CUs).  Splitting the rows
+    into SPLIT independent chunks (a batched GEMM) and adding the partial products fills the chip.
+    The summation order is fixed, so the step stays deterministic."""
+
+    SPLIT = 16                                              # divides B*64 for every B
+
+    @staticmethod
+    def forward(ctx, cols, wm, bias):
+        ctx.save_for_backward(cols, wm)
+        return torch.addmm(bias, cols, wm)
+
+    @staticmethod
+    def backward(ctx, gout):
+        cols, wm = ctx.saved_tensors
+        gout = gout.contiguous()
+        n, s = cols.shape[0], _PatchGemm.SPLIT
+        gcols = gout @ wm.t() if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(cols.view(s, n // s, -1).transpose(1, 2), gout.view(s, n // s, -1)).sum(dim=0)
+        return gcols, gw, gout.sum(dim=0)
+
+
 def im2col3x3(x):
     """x [B,8,8,C] fp32 -> [B*64, 9*C], columns ordered (ky, kx, c).  CUDA tensors go through the HIP
     kernels; the torch expression below is the same map for CPU tensors (unit tests of the module
@@ -171,7 +196,7 @@ class TrainTower(nn.Module):
         """x [B,8,8,Cin] -> [B,8,8,Cout]; kernel OIHW viewed as [(ky,kx,c), o]."""
         b, cin = x.shape[0], x.shape[3]
         wm = conv.weight.permute(2, 3, 1, 0).reshape(9 * cin, -1)
-        return torch.addmm(conv.bias, im2col3x3(x), wm).view(b, 8, 8, -1)
+        return _PatchGemm.apply(im2col3x3(x), wm, conv.bias).view(b, 8, 8, -1)
 
     @staticmethod
     def _conv1x1(x, conv):
