@@ -555,6 +555,9 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
         case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
         case 204: kern = crl_tower::k_trunk128_pipe<4>; break;                 // staggered staging
+        case 216: kern = crl_tower::k_trunk128_pipe<16>; break;                // x reads for dx = 0 only
+        case 232: kern = crl_tower::k_trunk128_pipe<32>; break;                // no vmcnt wait for the DMA
+        case 234: kern = crl_tower::k_trunk128_pipe<34>; break;                // ... and no barrier
         case 300: CRL_GEN(128, 4); break;                                      // the template at F = 128
         default: break;
         }

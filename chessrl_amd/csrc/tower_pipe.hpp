@@ -107,7 +107,8 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
 }
 
 // DIAG = 0: production.  Timing-only builds (WRONG results): bit 0 = no weight staging in the loop,
-// bit 1 = no per-tile barrier.  Bit 2 (correct results) = staggered staging: waves 0-3 stage at the
+// bit 1 = no per-tile barrier, bit 4 (16) = activation fragments read for the dx = 0 taps only (what a
+// cross-lane generation of the dx = +-1 fragments would leave).  Bit 2 (correct results) = staggered staging: waves 0-3 stage at the
 // mid-step barrier, waves 4-7 half a K-step later (measured 2 % slower than staging together).
 // BITS = 1: `planes` holds 128 plane bitboards per board (expand_bitplanes) instead of fp16 planes.
 template <int DIAG = 0, int BITS = 0>
@@ -205,8 +206,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
         auto fetch = [&](auto IC, int blk, bool next_blk, Frags &f) {
             constexpr int i = decltype(IC)::value;
             constexpr int kc = (i >> 2) & 1, s4 = i & 3;
-            f.x[0] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][0]);
-            f.x[1] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][1]);
+            if constexpr (!(DIAG & 16) || (i >> 3) == 1) {          // DIAG 16: only the dx = 0 taps read x
+                f.x[0] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][0]);
+                f.x[1] = lds_read16_asm<(kc * 8 + 2 * s4) * 16>(ab[next_blk ? 3 : (i >> 3)][1]);
+            }
             const int wb = lds_base + P2_WRING_OFF +
                            ((t_conv0 + 6 * blk + (i >> 2)) & (PIPE_RING - 1)) * WTILE_BYTES;
             f.w[0] = lds_read16_asm<0>(wb + waddr[0][s4]);
@@ -237,8 +240,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                 if constexpr ((i & 3) == 2) {
                     // middle of K-step t: publish tile t+1 (its first read is issued one sub-step
                     // before its K-step starts), recycle the buffer of tile t-1 for tile t+3
-                    if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(DIAG & 32)) {                  // DIAG 32 (timing only): do not wait for the DMA
+                        if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                     if (!(DIAG & 2)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(DIAG & 1) && t + 3 < n_tiles && (!(DIAG & 4) || wave < 4))
@@ -262,8 +267,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                     }
                 }
                 // operands of THIS sub-step have landed; the 4 reads just issued may be in flight
-                if (issued) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                constexpr int nxt = wrap ? 0 : i + 1;
+                if (!issued) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if constexpr ((DIAG & 16) && (nxt >> 3) != 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (i % 2 == 0) mfma4(f0);
                 else mfma4(f1);
