@@ -185,3 +185,17 @@ def test_choose_children_equals_per_game_compute_policy():
             q = mcts_oracle.compute_policy(list(visits[g, :nchild[g]]), int(root[g]), int(plies[g]), noise=False)
             if not noise:
                 assert got[g] == int(np.argmax(q))
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py measures the HIP path only: on a box without a GPU it must exit with an error,
+    not fall back to anything."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert "MI355X" in (r.stderr + r.stdout) and "{" not in r.stdout
