@@ -27,7 +27,7 @@ FLAG_NUMPY_LEGACY = 1
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
-    "crl_max_sims", "crl_set_window", "crl_set_plane_format", "crl_copy_game", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
+    "crl_max_sims", "crl_set_window", "crl_set_plane_format", "crl_copy_game", "crl_copy_game_from", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_push_sequences", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
@@ -89,6 +89,7 @@ def lib():
     L.crl_max_sims.argtypes = [vp]
     L.crl_set_window.argtypes = [vp, i32, i32]
     L.crl_copy_game.argtypes = [vp, i32, i32]
+    L.crl_copy_game_from.argtypes = [vp, i32, vp, i32]
     L.crl_uci_label_moves.argtypes = [vp]
     L.crl_reset_games.argtypes = [vp, vp]
     L.crl_set_positions.argtypes = [vp, vp, i32]
@@ -178,6 +179,10 @@ class Context(object):
 
     def copy_game(self, dst, src):
         self._ck(self._L.crl_copy_game(self._h, dst, src), "crl_copy_game")
+
+    def copy_game_from(self, dst, src_ctx, src):
+        """Slot ``dst`` becomes a deep copy of slot ``src`` of another context on the same GPU."""
+        self._ck(self._L.crl_copy_game_from(self._h, dst, src_ctx._h, src), "crl_copy_game_from")
 
     def sync(self):
         self._ck(self._L.crl_sync(self._h), "crl_sync")

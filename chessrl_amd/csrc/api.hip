@@ -261,6 +261,20 @@ int crl_copy_game(crl_ctx *ctx, int dst, int src)
     return CRL_OK;
 }
 
+int crl_copy_game_from(crl_ctx *ctx, int dst, crl_ctx *src_ctx, int src)
+{
+    if (!ctx || !src_ctx || dst < 0 || src < 0 || dst >= ctx->d.G || src >= src_ctx->d.G)
+        return fail(ctx, CRL_ERR_ARG, "crl_copy_game_from: bad slot");
+    if (ctx->device != src_ctx->device)
+        return fail(ctx, CRL_ERR_ARG, "crl_copy_game_from: both contexts must live on one GPU");
+    if (src_ctx == ctx) return crl_copy_game(ctx, dst, src);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (src_ctx->stream != ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(src_ctx->stream));
+    hipLaunchKernelGGL(k_copy_game_across, dim3(1), dim3(64), 0, ctx->stream, ctx->d, dst, src_ctx->d, src);
+    HIP_TRY(ctx, hipGetLastError());
+    return check_dev_error(ctx);
+}
+
 const char *crl_last_error(crl_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 int crl_max_games(crl_ctx *ctx) { return ctx ? ctx->d.G : CRL_ERR_ARG; }
 int crl_max_sims(crl_ctx *ctx) { return ctx ? ctx->d.N - 1 : CRL_ERR_ARG; }

@@ -375,6 +375,28 @@ __global__ __launch_bounds__(64) void k_copy_game(Dev d, int dst, int src)
     }
 }
 
+// Tree.__init__ (mctree.py:105-109: ``Node(root.get_copy())``) when the caller's Game lives in another
+// context (the Game arena) than the search engine: the same deep copy across two contexts of one GPU.
+__global__ __launch_bounds__(64) void k_copy_game_across(Dev d, int dst, Dev sd, int src)
+{
+    const int lane = threadIdx.x;
+    const int p = sd.ply[src];
+    if (p > d.MAXPLY) { if (lane == 0) dev_error(d, DERR_PLY_POOL); return; }
+    for (int i = lane; i < HIST_RING; i += 64) {
+        d.hist[(size_t)dst * HIST_RING + i] = sd.hist[(size_t)src * HIST_RING + i];
+        d.hist_hash[(size_t)dst * HIST_RING + i] = sd.hist_hash[(size_t)src * HIST_RING + i];
+    }
+    for (int i = lane; i < p; i += 64)
+        d.rec_moves[(size_t)dst * d.MAXPLY + i] = sd.rec_moves[(size_t)src * sd.MAXPLY + i];
+    if (lane == 0) {
+        d.cur[dst] = sd.cur[src];
+        d.ply[dst] = p;
+        d.game_result[dst] = sd.game_result[src];
+        d.root_dead[dst] = 1;
+        d.leaf_kind[dst] = LEAF_NONE;
+    }
+}
+
 // ---- SelfPlayTree seam kernels -------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
 {

@@ -213,6 +213,15 @@ class LockstepEngine(object):
         self._eval_into(self.planes_s1, self.pol_s1, None)
         return self.ctx.greedy_moves(self.pol_s1.data_ptr(), mask=mask, push=push)
 
+    def load_games(self, games):
+        """Slot i becomes a deep copy of ``games[i]`` (chessrl_amd ``Game`` objects: position,
+        move stack and history as they stand, whatever position they started from)."""
+        from .game import arena
+        self._bind_stream()
+        src = arena().ctx
+        for i, g in enumerate(games):
+            self.ctx.copy_game_from(i, src, g._slot)
+
     def load_moves(self, move_lists):
         """Replay per-slot move id sequences from the start position (tests / Game copies)."""
         self.reset()

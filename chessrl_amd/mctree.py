@@ -2,11 +2,16 @@
 
 Same surface as /root/reference/src/chessrl/mctree.py:148-198: construct from a ``Game``,
 call ``search_move(agent, max_iters, verbose, noise, ai_move)``, then read
-``tree.root.visits`` and ``tree.root.children[i].visits / .value / .prior``.  The tree
-itself lives in HBM (flat node/edge arrays, one wavefront per game); select / expand /
+``tree.root.visits`` and ``tree.root.children[i].visits / .value / .prior / .state``.  The
+tree itself lives in HBM (flat node/edge arrays, one wavefront per game); select / expand /
 backup are the HIP kernels behind crl_sim_* and the final ``compute_policy``
 (mctree.py:305-322) stays on the host in numpy so that the Dirichlet noise comes from the
 same ``np.random`` stream as the reference's.
+
+The root is the caller's game as it stands -- whatever position it was set up from (standard
+start, FEN, board row) and whatever moves were pushed since: the search engine's slot is a
+device-side deep copy of the Game's arena slot (``crl_copy_game_from``), the counterpart of
+``Node(root.get_copy())`` in mctree.py:105-109.
 
 ``threads`` is accepted for signature compatibility; simulations run with the
 reference's sequential (threads=1) semantics, its only deterministic mode.
@@ -14,23 +19,35 @@ reference's sequential (threads=1) semantics, its only deterministic mode.
 import numpy as np
 
 from .engine import compute_policy
-from .game import Game, move_to_uci
+from .game import Game, arena, move_to_uci
 from . import _lib
 
 
 class Node(object):
-    """Read-only view of one root child (``state`` is not materialised)."""
+    """Read-only view of one root child.  ``state`` (the child's Game: root + our move + the
+    stored reply) is built on first access; the device tree keeps only boards."""
 
-    def __init__(self, visits, value, prior, move, reply):
+    def __init__(self, root_game, visits, value, prior, move, reply):
         self.visits, self.value, self.prior = int(visits), float(value), np.float32(prior)
         self.move, self.reply = move, reply
         self.vloss = 0
         self.children = []
+        self._root_game, self._state = root_game, None
+
+    @property
+    def state(self):
+        if self._state is None:
+            g = self._root_game.get_copy()
+            g.move(self.move)
+            if self.reply is not None:
+                g.move(self.reply)
+            self._state = g
+        return self._state
 
 
 class _Root(object):
-    def __init__(self, visits, children):
-        self.visits, self.children = int(visits), children
+    def __init__(self, game, visits, children):
+        self.state, self.visits, self.children = game, int(visits), children
         self.parent = None
 
 
@@ -39,7 +56,7 @@ class Tree(object):
         if not isinstance(root, Game):
             raise TypeError("root must be a chessrl_amd Game")
         self._game = root
-        self.root = _Root(1, [])
+        self.root = _Root(root, 1, [])
 
 
 class SelfPlayTree(Tree):
@@ -49,26 +66,30 @@ class SelfPlayTree(Tree):
         self.num_threads = threads
 
     def search_move(self, agent, max_iters=200, verbose=False, noise=True, ai_move=False):
+        game = self._game
         eng = agent.engine_for(max_iters)
-        ids = self._game.move_ids()
-        eng.load_moves([list(ids)])
+        eng.ctx.copy_game_from(0, arena().ctx, game._slot)
         eng.search(max_iters)
         rc = eng.root_children()
         n = int(rc["nchild"][0])
-        kids = [Node(rc["visits"][0, k], rc["values"][0, k], rc["priors"][0, k],
-                     move_to_uci(rc["moves"][0, k]),
-                     None if rc["replies"][0, k] == _lib.NO_MOVE else move_to_uci(rc["replies"][0, k]))
-                for k in range(n)]
-        self.root = _Root(rc["root_visits"][0], kids)
-        policy = compute_policy([c.visits for c in kids], self.root.visits, len(ids), noise=noise)
+        if n == 0:
+            # a finished root has no children; the reference's np.argmax([]) raises here too
+            raise ValueError("search_move on a finished game (attempt to get argmax of an empty sequence)")
+        kids = []
+        for k in range(n):
+            reply = rc["replies"][0, k]
+            kids.append(Node(game, rc["visits"][0, k], rc["values"][0, k], rc["priors"][0, k],
+                             move_to_uci(rc["moves"][0, k]),
+                             None if reply == _lib.NO_MOVE else move_to_uci(reply)))
+        self.root = _Root(game, rc["root_visits"][0], kids)
+        stack = game.move_ids()
+        policy = compute_policy([c.visits for c in kids], self.root.visits, len(stack), noise=noise)
         best = kids[int(np.argmax(policy))]
+        # mctree.py:185-194 reads the last two entries of the chosen child's move stack
         if best.reply is not None:
-            b_mov, agent_last_mov = best.move, best.reply
-        else:
-            # the game ended on our move: the reference returns move_stack[-2:] of the child,
-            # i.e. (previous ply, our move) (mctree.py:185-188), or two NULL moves on IndexError
-            if len(ids) >= 1:
-                b_mov, agent_last_mov = move_to_uci(ids[-1]), best.move
-            else:
-                b_mov = agent_last_mov = Game.NULL_MOVE
-        return (b_mov, agent_last_mov) if ai_move else b_mov
+            pair = (best.move, best.reply)
+        elif len(stack) >= 1:                    # game over after our move: (previous ply, our move)
+            pair = (move_to_uci(stack[-1]), best.move)
+        else:                                    # one-entry stack: the IndexError branch
+            pair = (Game.NULL_MOVE, Game.NULL_MOVE)
+        return pair if ai_move else pair[0]

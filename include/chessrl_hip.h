@@ -99,6 +99,12 @@ int  crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n);
 /* Game.get_copy (game.py:79-80): slot dst becomes a deep copy (board AND move stack) of
  * slot src; absolute slot numbers, independent of the window. */
 int  crl_copy_game(crl_ctx *ctx, int dst, int src);
+/* Tree.__init__ (mctree.py:105-109, ``Node(root.get_copy())``) and Game(board=other.board) when the
+ * two games live in different contexts of one GPU (the Game arena and a search engine): slot dst
+ * of ctx becomes a deep copy of slot src of src_ctx -- position, move stack and the history the
+ * encoder and the repetition rule read -- whatever position the source game started from.
+ * The record must fit ctx's max_plies (CRL_ERR_CAPACITY otherwise).  Absolute slot numbers. */
+int  crl_copy_game_from(crl_ctx *ctx, int dst, crl_ctx *src_ctx, int src);
 /* Game.get_legal_moves (game.py:43-57): python-chess generation order. */
 int  crl_legal_moves(crl_ctx *ctx, uint16_t *moves /*G x 256*/, int32_t *counts /*G*/);
 /* Game.move (game.py:28-41): applied iff in the legal list; ok[g] = 1/0; CRL_NO_MOVE skips. */

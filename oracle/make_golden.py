@@ -14,6 +14,14 @@ Run in the authoring container only (needs /root/reference):
                       reference code as it runs under this image's numpy 2.x; "legacy" feeds
                       it float64-widened priors, which makes ``10 * prior`` a float64 product
                       exactly as numpy 1.17.2 (requirements.txt:6) would compute it.
+                      Round 2 adds the paths the random prefixes never reach: roots set up from
+                      a FEN whose trees contain fifty-move claims, stalemates, mates after our
+                      move (state = S1, mctree.py:241-246 skipped) and after the reply, terminal
+                      nodes re-selected (mctree.py:218), a root whose chosen child ends the game
+                      on our move (the ``move_stack[-2:]`` tuple, mctree.py:185-194, with and
+                      without the IndexError branch), the 218-move position, a 120-ply quiet
+                      game (halfmove clock > 100 plies deep into the ring) and 800-simulation
+                      trees (the AlphaZero budget BASELINE.json's metric is quoted on).
 
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 """
@@ -25,7 +33,7 @@ import struct
 import numpy as np
 
 from . import mcts_oracle, ref_loader
-from .chess_oracle import OracleGame, move_to_uci
+from .chess_oracle import OracleGame, board_from_fen, move_to_uci
 from .fakenet import FakeNet
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -62,6 +70,104 @@ CASES = [
     (9, 10, 11, 30, 0, 140, True),
     (10, 28, 12, 31, 0, 140, True),
 ]
+
+
+def quiet_game(seed, plies, min_clock=0):
+    """A long game of mostly quiet piece moves: the halfmove clock climbs (to at least
+    ``min_clock``: later draws are tried until one gets there) and the repetition scan has a long
+    reversible tail to walk."""
+    rng = np.random.default_rng(seed)
+    while True:
+        g = OracleGame()
+        while len(g) < plies and g.get_result() is None:
+            b = g.board_at(0)
+            occ = 0
+            for t in range(6):
+                occ |= int(b.bb[t])
+            lm = g.legal_move_ids()
+            quiet = [m for m in lm if not (int(b.bb[0]) >> (m & 63)) & 1 and not (occ >> ((m >> 6) & 63)) & 1]
+            pool = quiet if quiet and rng.random() < 0.97 else lm
+            g.move(move_to_uci(pool[int(rng.integers(len(pool)))]))
+        if g.get_result() is None and ((int(g.board_at(0).state) >> 12) & 255) >= min_clock:
+            return g
+
+
+MAX_MOVES_FEN = "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1"
+
+# Round-2 cases: dicts.  "fen" = root set up with an EMPTY move stack (python-chess Board(fen)),
+# then "moves" pushed; "quiet" = quiet_game(seed, plies) from the standard position.
+CASES2 = [
+    dict(name="claim_clock96_w", fen="8/8/8/4k3/8/8/4K3/7R w - - 96 80", net=13, shift=30, sims=90),
+    dict(name="claim_clock97_b", fen="8/8/8/4k3/8/8/4K3/7R b - - 97 80", net=13, shift=30, sims=90),
+    dict(name="claim_clock99_b", fen="8/8/8/4k3/8/8/3QK3/8 b - - 99 90", net=14, shift=29, sims=60),
+    dict(name="mate_or_stalemate_in_one", fen="7k/8/5KQ1/8/8/8/8/8 w - - 0 1", net=13, shift=30, sims=90),
+    dict(name="back_rank_mate_no_stack", fen="6k1/5ppp/8/8/8/8/5PPP/R5K1 w - - 0 1", net=13, shift=30, sims=90),
+    dict(name="back_rank_mate_tuple_quirk", fen="6k1/p4ppp/8/8/8/8/5PPP/1R4K1 b - - 0 1",
+         moves=["a7a6"], net=15, shift=30, sims=120),
+    dict(name="single_reply_black", fen="k7/8/1K6/8/8/8/8/2Q5 b - - 10 1", net=13, shift=30, sims=90),
+    dict(name="castling_both_sides", fen="r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", net=13, shift=30, sims=90),
+    dict(name="ep_and_promotions", fen="n1n5/PPPk4/8/8/4Pp2/8/4Kppp/5N1N b - e3 0 1", net=16, shift=28, sims=110),
+    dict(name="max_moves_218", fen=MAX_MOVES_FEN, net=3, shift=30, sims=240),
+    dict(name="quiet_120_plies", quiet=(77, 120), net=41, shift=31, sims=120),
+    dict(name="quiet_170_plies", quiet=(78, 170), net=42, shift=29, sims=100),
+    dict(name="quiet_clock_over_90", quiet=(79, 130, 92), net=43, shift=31, sims=160),
+    dict(name="fivefold_on_our_move", fen="8/8/8/4k3/8/8/4K3/7R w - - 0 1",
+         moves=["h1h2", "e5e6", "h2h1", "e6e5"] * 3 + ["h1h2", "e5e6", "h2h1"], net=21, shift=30, sims=60),
+    dict(name="sims800_deep", prefix=(2, 7), net=4, shift=31, sims=800),
+    dict(name="sims800_wide", prefix=(11, 40), net=19, shift=26, sims=800),
+]
+
+
+def case2_game(c):
+    if "fen" in c:
+        g = OracleGame(board=board_from_fen(c["fen"]))
+    elif "quiet" in c:
+        g = quiet_game(*c["quiet"])
+    else:
+        g = prefix_game(*c["prefix"])
+    for u in c.get("moves", []):
+        assert g.move(u), (c["name"], u)
+    return g
+
+
+def run_case2(mct, c, mode):
+    g = case2_game(c)
+    net = FakeNet(seed=c["net"], prior_shift=c["shift"], quant=c.get("quant", 0))
+    agent = mcts_oracle.OracleAgent(net, widen_priors=(mode == "legacy"))
+    tree = mct.SelfPlayTree(g, threads=1)
+    bm, am = tree.search_move(agent, max_iters=c["sims"], noise=False, ai_move=True)
+    kids = tree.root.children
+    pol = tree.compute_policy(tree.root, noise=False)
+    chosen = int(np.argmax(pol)) if len(kids) else -1
+
+    def count(n, pred):
+        return int(pred(n)) + sum(count(k, pred) for k in n.children)
+
+    return {
+        "name": c["name"], "fen": c.get("fen"), "mode": mode,
+        "net_seed": c["net"], "prior_shift": c["shift"], "quant": c.get("quant", 0), "tie": False,
+        "sims": c["sims"],
+        # moves on the root's move stack (pushed after "fen", or from the standard position)
+        "prefix_moves": [m.uci() for m in g.board.move_stack],
+        "root_result": g.get_result(),
+        "visits": [int(k.visits) for k in kids],
+        "values": [f64hex(k.value) for k in kids],
+        "priors": [f32hex(k.prior) for k in kids],
+        "root_visits": int(tree.root.visits),
+        "bm": bm, "am": am, "chosen": chosen,
+        "chosen_child_result": kids[chosen].state.get_result() if chosen >= 0 else None,
+        "chosen_child_stack": len(kids[chosen].state.board.move_stack) if chosen >= 0 else 0,
+        "policy": [f64hex(p) for p in pol],
+        "n_evals": agent.n_evals,
+        "n_nodes": count(tree.root, lambda n: True),
+        "n_terminal_nodes": count(tree.root, lambda n: n.state.get_result() is not None),
+        "terminal_visits": sum_terminal_visits(tree.root),
+    }
+
+
+def sum_terminal_visits(n):
+    own = n.visits if n.state.get_result() is not None else 0
+    return int(own) + sum(sum_terminal_visits(k) for k in n.children)
 
 
 def run_case(mct, case, mode):
@@ -107,6 +213,20 @@ def main():
         json.dump({"source": "mctree.SelfPlayTree.search_move (mctree.py:159-198) imported from "
                              "/root/reference with a stub game module; numpy %s" % np.__version__,
                    "cases": cases}, f)
+    cases2 = []
+    for c in CASES2:
+        a = run_case2(mct, c, "nep50")
+        b = run_case2(mct, c, "legacy")
+        a["differs_from_other_mode"] = b["differs_from_other_mode"] = a["visits"] != b["visits"]
+        cases2 += [a, b]
+        print(c["name"], "children", len(a["visits"]), "nodes", a["n_nodes"], "terminal nodes",
+              a["n_terminal_nodes"], "terminal visits", a["terminal_visits"], "moves", (a["bm"], a["am"]),
+              "chosen child result", a["chosen_child_result"], "modes differ", a["visits"] != b["visits"])
+    with open(os.path.join(OUT, "mcts_cases_r2.json"), "w") as f:
+        json.dump({"source": "mctree.SelfPlayTree.search_move (mctree.py:159-198) imported from "
+                             "/root/reference with a stub game module; numpy %s; roots from FENs / long "
+                             "quiet games / 800 simulations" % np.__version__,
+                   "cases": cases2}, f)
     print("wrote", OUT)
 
 

@@ -1,0 +1,176 @@
+"""GPU parity at the BASELINE workload sizes (BASELINE.json configs C2, C3 and the 800-simulation
+budget the metric is quoted on).
+
+* 800 simulations per move on eight different roots, bit-exact against the CPU oracle
+  (mctree.py:159-303 restated in oracle/mcts_oracle.py, itself pinned by the reference-run
+  goldens incl. two 800-simulation trees).
+* A soak of complete self-play games (noise on, refill, compaction of the thinning batch)
+  against the oracle's games, move for move.
+* C2 (512 games x 100 sims, 6x64 tower) and C3 (4096 games x 800 sims, 10x128 tower) for one
+  whole move with the real fused tower, where the oracle cannot follow (no bit-identical tower on
+  the CPU): size-independent properties of mctree.py instead -- root.visits == S+1
+  (mctree.py:111,291), the children's visits sum to S (every simulation passes through exactly
+  one root child), one node per simulation at most (mctree.py:231-257), the device counters
+  agree with each other, no pool overflowed (crl_sync), every chosen move and stored reply is
+  accepted by Game.move's legality test in an independent rules context and leads to the
+  position the tree stored, and a second run from the same seeds gives identical visit counts.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcts_oracle
+from oracle.chess_oracle import uci_to_move, move_to_uci
+from oracle.fakenet import FakeNet
+
+from tests.test_gpu_search import move_ids, random_prefix_games
+from tests.util import oracle_games_parallel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_800_simulations_on_eight_roots_match_oracle():
+    from chessrl_amd.engine import LockstepEngine
+    G, sims = 8, 800
+    games = random_prefix_games(G, 70, seed=808)
+    net = FakeNet(seed=80, prior_shift=31)
+    eng = LockstepEngine(net.to("cuda:0"), n_games=G, max_sims=sims)
+    eng.load_moves([move_ids(g) for g in games])
+    eng.search(sims)
+    rc = eng.root_children()
+    cnt = eng.ctx.counters()
+    assert cnt["sims"] == G * sims and cnt["nodes"] + cnt["terminal_hits"] == cnt["sims"]
+    deepest = 0
+    for i, g in enumerate(games):
+        r = mcts_oracle.search(g, mcts_oracle.OracleAgent(net), sims, noise=False)
+        n = rc["nchild"][i]
+        assert list(rc["visits"][i, :n]) == r.visits, i
+        assert rc["root_visits"][i] == r.root_visits == sims + 1
+        assert [move_to_uci(m) for m in rc["moves"][i, :n]] == r.child_moves
+        exp_rep = [0xFFFF if u == "00000" else uci_to_move(u) for u in r.child_replies]
+        assert list(rc["replies"][i, :n]) == exp_rep
+        assert np.array_equal(rc["values"][i, :n].view(np.uint64),
+                              np.array(r.values, dtype=np.float64).view(np.uint64)), i
+        assert np.array_equal(rc["priors"][i, :n], np.array(r.priors, dtype=np.float32)), i
+        deepest = max(deepest, r.max_depth)
+    assert deepest >= 8                      # the trees are deep, not 800 children of the root
+    eng.close()
+
+
+def test_soak_of_complete_games_matches_oracle():
+    """40 complete self-play games through 16 lockstep slots: refill while games remain, then
+    compaction of the thinning batch; Dirichlet noise on, per-game streams."""
+    from chessrl_amd.selfplay import SelfPlayRunner, game_color
+    n, sims, seed = 40, 8, 31
+    net = FakeNet(seed=77, prior_shift=30)
+    run = SelfPlayRunner(net.to("cuda:0"), n_parallel=16, sims=sims, seed=seed, noise=True,
+                         total_games=n, max_plies=2048)
+    run.COMPACT_MIN = 4
+    recs = {r.game_id: r for r in run.run()}
+    assert sorted(recs) == list(range(n))
+    plies = 0
+    hist = oracle_games_parallel(dict(seed=77, prior_shift=30), seed, sims,
+                                 [(gid, game_color(seed, gid)) for gid in sorted(recs)])
+    for gid in sorted(recs):
+        h = hist[gid]
+        assert recs[gid].get_history()["moves"] == h["moves"], gid
+        assert recs[gid].result == h["result"] and h["result"] is not None
+        plies += len(h["moves"])
+    assert plies > 4000 and run.G < 16       # long games, and the batch was compacted
+    run.close()
+
+
+def _open_with_random_plies(eng, seed, max_plies):
+    """Slot g plays g % (max_plies+1) seeded random legal moves, in lockstep, through the C-ABI."""
+    G = eng.G
+    rng = np.random.default_rng(seed)
+    want = np.arange(G) % (max_plies + 1)
+    for k in range(max_plies):
+        moves, counts = eng.ctx.legal_moves()
+        pick = np.full(G, 0xFFFF, dtype=np.uint16)
+        live = (want > k) & (counts > 0)
+        idx = (rng.random(G) * np.maximum(counts, 1)).astype(np.int64)
+        pick[live] = moves[np.arange(G), idx][live]
+        eng.ctx.push_moves(pick)
+
+
+def _one_move_at_size(G, sims, blocks, filters, seed):
+    from chessrl_amd import _lib
+    from chessrl_amd.engine import LockstepEngine, choose_children
+    from chessrl_amd.model import ChessModel
+    model = ChessModel(blocks=blocks, filters=filters, seed=seed)
+    assert model.fused
+    eng = LockstepEngine(model, n_games=G, max_sims=sims, max_plies=512)
+    eng.reset()
+    _open_with_random_plies(eng, seed, 11)
+    live = eng.ctx.results() == _lib.RESULT_NONE          # a random opening may already be mated
+    assert live.mean() > 0.99
+    before = eng.ctx.get_positions()
+    _, plies0, _ = eng.ctx.records(with_moves=False)
+    c0 = eng.ctx.counters()
+    eng.search(sims)
+    eng.ctx.sync()                                        # no node / edge / ply pool overflowed
+    rc = eng.root_children()
+    c1 = eng.ctx.counters()
+    d = {k: c1[k] - c0[k] for k in c1}
+    nchild, visits = rc["nchild"], rc["visits"]
+    L = int(live.sum())
+    cols = np.arange(visits.shape[1])[None, :]
+    iskid = cols < nchild[:, None]
+    vis = np.where(iskid, visits, 0)
+    # --- mctree.py invariants
+    assert (rc["root_visits"][live] == sims + 1).all() and (nchild[~live] == 0).all()
+    assert (vis.sum(axis=1)[live] == sims).all()
+    assert (nchild[live] >= 1).all() and (nchild <= np.minimum(sims, 218)).all()
+    assert (visits[iskid] >= 1).all()                     # a created child was visited
+    assert d["sims"] == L * sims
+    assert d["nodes"] + d["terminal_hits"] == d["sims"]
+    assert d["depth_sum"] >= d["sims"] and d["branch_sum"] >= d["nodes"]
+    assert L <= d["evals"] <= L + 2 * d["nodes"]
+    assert np.isfinite(rc["values"][iskid]).all()
+    assert (np.abs(rc["values"][iskid]) <= visits[iskid] + 1e-9).all()   # |v| <= 1 per visit
+    # --- the move the reference would play (noise off) and its stored reply are legal
+    chosen = choose_children(visits, nchild, rc["root_visits"], plies0, noise=False)
+    assert ((chosen >= 0) == live).all()
+    rows = np.arange(G)
+    pick = np.maximum(chosen, 0)
+    bm = np.where(live, rc["moves"][rows, pick], _lib.NO_MOVE).astype(np.uint16)
+    am = np.where(live, rc["replies"][rows, pick], _lib.NO_MOVE).astype(np.uint16)
+    got_bm, got_am = eng.advance(chosen)
+    assert np.array_equal(got_bm, bm) and np.array_equal(got_am, am)
+    after = eng.ctx.get_positions()
+    _, plies1, res1 = eng.ctx.records(with_moves=False)
+    rules = _lib.Context(G, 1, max_plies=512)             # independent rules context: Game.move
+    rules.set_positions(before)
+    assert (rules.push_moves(bm).astype(bool) == live).all()
+    over_after_bm = rules.results() != _lib.RESULT_NONE
+    assert ((am == _lib.NO_MOVE) == over_after_bm).all()  # no reply exactly when the game is over
+    ok = rules.push_moves(am)
+    assert (ok.astype(bool) == ~over_after_bm).all()
+    assert np.array_equal(rules.get_positions(), after)
+    assert np.array_equal(rules.results()[live], res1[live])
+    assert np.array_equal((plies1 - plies0)[live], np.where(over_after_bm, 1, 2)[live])
+    rules.close()
+    out = dict(visits=vis.copy(), nchild=nchild.copy(), depth=d["depth_sum"] / d["sims"],
+               branch=d["branch_sum"] / max(1, d["nodes"]), terminal=d["terminal_hits"])
+    eng.close()
+    return out
+
+
+def test_c2_size_one_move_properties_and_rerun_is_identical():
+    """BASELINE config C2: 512 games, 100 sims/move, 6-block/64-filter tower."""
+    a = _one_move_at_size(512, 100, 6, 64, seed=2)
+    b = _one_move_at_size(512, 100, 6, 64, seed=2)
+    assert np.array_equal(a["visits"], b["visits"]) and np.array_equal(a["nchild"], b["nchild"])
+    print("C2 one move: mean depth %.2f, mean branching %.1f, terminal hits %d" % (
+        a["depth"], a["branch"], a["terminal"]))
+
+
+def test_c3_size_one_move_properties():
+    """BASELINE config C3 (= one GPU's shard of C4): 4096 games, 800 sims/move, 10x128 tower:
+    N = 801 nodes per tree, the 14-GB edge pool, the full-size trunk launch."""
+    a = _one_move_at_size(4096, 800, 10, 128, seed=3)
+    assert a["depth"] > 2.0
+    print("C3 one move: mean depth %.2f, mean branching %.1f, terminal hits %d" % (
+        a["depth"], a["branch"], a["terminal"]))
+    torch.cuda.empty_cache()

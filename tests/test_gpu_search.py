@@ -398,6 +398,53 @@ def test_search_matches_committed_golden_vectors(golden_dir):
         eng.close()
 
 
+def test_dropin_tree_matches_round2_golden_vectors(golden_dir):
+    """tests/golden/mcts_cases_r2.json -- the reference's own mctree.py on roots set up from FENs
+    (fifty-move claims, mates / stalemates / fivefold repetition reached by our move or by the
+    reply, terminal nodes re-selected, mctree.py:216-229,241-246,266-268), the two shapes of the
+    ``move_stack[-2:]`` tuple when the chosen child ends the game (mctree.py:185-194), the 218-move
+    root, long quiet games and 800-simulation trees -- through the drop-in objects: ``Game`` (FEN +
+    pushed moves), ``Agent``, ``SelfPlayTree.search_move``.  The engine slot is a device copy of
+    the Game's slot (crl_copy_game_from), so a game that did not start from the standard position
+    is searched from its real root."""
+    import json
+    import os
+    import struct
+    from chessrl_amd import mctree
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.engine import compute_policy
+    from chessrl_amd.game import Game
+    cases = json.load(open(os.path.join(golden_dir, "mcts_cases_r2.json")))["cases"]
+    assert len(cases) >= 30
+    agents = {}
+    for c in cases:
+        key = (c["net_seed"], c["prior_shift"], c["quant"], c["mode"])
+        if key not in agents:
+            net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"], quant=c["quant"])
+            agents[key] = Agent(True, model=net.to("cuda:0"), numpy_promotion=c["mode"])
+        g = Game(board=c["fen"]) if c["fen"] else Game()
+        for u in c["prefix_moves"]:
+            assert g.move(u), (c["name"], u)
+        assert g.get_result() is None and len(g) == len(c["prefix_moves"])
+        tree = mctree.SelfPlayTree(g, threads=1)
+        mv = tree.search_move(agents[key], max_iters=c["sims"], noise=False, ai_move=True)
+        kids = tree.root.children
+        tag = (c["name"], c["mode"])
+        assert [k.visits for k in kids] == c["visits"], tag
+        assert tree.root.visits == c["root_visits"] == c["sims"] + 1
+        assert [struct.pack(">d", k.value).hex() for k in kids] == c["values"], tag
+        assert [struct.pack(">f", k.prior).hex() for k in kids] == c["priors"], tag
+        pol = compute_policy([k.visits for k in kids], tree.root.visits, len(g), noise=False)
+        assert [struct.pack(">d", p).hex() for p in pol] == c["policy"], tag
+        assert int(np.argmax(pol)) == c["chosen"]
+        assert mv == (c["bm"], c["am"]), tag
+        best = kids[c["chosen"]]
+        assert best.state.get_result() == c["chosen_child_result"]        # Node.state, built lazily
+        assert len(best.state) == c["chosen_child_stack"]
+        best.state.free()
+        g.free()
+
+
 def test_f64_sqrt_and_divide_are_correctly_rounded():
     """The PUCT contract leans on IEEE float64 sqrt/divide on the device: check them against
     numpy through the tower-free path (a torch kernel uses the same hardware ops)."""

@@ -8,17 +8,17 @@ import numpy as np
 import pytest
 
 from oracle import mcts_oracle, ref_loader
-from oracle.chess_oracle import OracleGame
+from oracle.chess_oracle import OracleGame, board_from_fen
 from oracle.fakenet import FakeNet
 
 
-def load_cases(golden_dir):
-    with open(os.path.join(golden_dir, "mcts_cases.json")) as f:
+def load_cases(golden_dir, name="mcts_cases.json"):
+    with open(os.path.join(golden_dir, name)) as f:
         return json.load(f)["cases"]
 
 
 def case_game(c):
-    g = OracleGame()
+    g = OracleGame(board=board_from_fen(c["fen"])) if c.get("fen") else OracleGame()
     for u in c["prefix_moves"]:
         assert g.move(u)
     return g
@@ -38,8 +38,13 @@ def test_golden_has_a_case_where_numpy_modes_differ(golden_dir):
     assert {c["mode"] for c in cases} == {"nep50", "legacy"}
 
 
-def test_oracle_matches_golden_vectors(golden_dir):
-    for c in load_cases(golden_dir):
+@pytest.mark.parametrize("fixture", ["mcts_cases.json", "mcts_cases_r2.json"])
+def test_oracle_matches_golden_vectors(golden_dir, fixture):
+    """mcts_cases_r2.json: roots from FENs (fifty-move claims, mates and stalemates on our move and
+    after the reply, fivefold repetition reached by our move, the (previous ply, our move) tuple of
+    mctree.py:185-194 with and without its IndexError branch), the 218-move root, 120-170-ply quiet
+    games and 800-simulation trees -- all outputs of the reference's own mctree.py."""
+    for c in load_cases(golden_dir, fixture):
         net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"], quant=c["quant"], tie=c["tie"])
         r = mcts_oracle.search(case_game(c), mcts_oracle.OracleAgent(net), c["sims"], noise=False,
                                mode=c["mode"])
@@ -49,6 +54,26 @@ def test_oracle_matches_golden_vectors(golden_dir):
         assert [struct.pack(">d", v).hex() for v in r.values] == c["values"]
         assert [struct.pack(">f", p).hex() for p in r.priors] == c["priors"]
         assert [struct.pack(">d", p).hex() for p in r.policy] == c["policy"]
+        if "n_nodes" in c:
+            assert r.n_nodes == c["n_nodes"] and r.chosen == c["chosen"]
+
+
+def test_round2_goldens_reach_the_terminal_paths(golden_dir):
+    """The fixture must keep exercising what it was made for (mctree.py:216-229,241-246,266-268,
+    185-194): terminal nodes re-selected, games ending on our move, both tuple-quirk shapes, the
+    218-child root and the 800-simulation budget."""
+    cs = {c["name"]: c for c in load_cases(golden_dir, "mcts_cases_r2.json") if c["mode"] == "nep50"}
+    assert sum(c["terminal_visits"] > c["n_terminal_nodes"] for c in cs.values()) >= 4   # re-selected
+    q = cs["back_rank_mate_tuple_quirk"]
+    assert q["chosen_child_result"] == 1 and (q["bm"], q["am"]) == ("a7a6", "b1b8")
+    assert q["chosen_child_stack"] == 2
+    n = cs["back_rank_mate_no_stack"]
+    assert n["chosen_child_result"] == 1 and (n["bm"], n["am"]) == ("00000", "00000")
+    f = cs["fivefold_on_our_move"]
+    assert f["chosen_child_result"] == 0 and (f["bm"], f["am"]) == ("h2h1", "e6e5")
+    assert len(cs["max_moves_218"]["visits"]) == 218
+    assert cs["quiet_clock_over_90"]["n_terminal_nodes"] > 0
+    assert sorted(c["sims"] for c in cs.values())[-2:] == [800, 800]
 
 
 @pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not present on this box")

@@ -30,3 +30,31 @@ def array_to_board(a):
 def oracle_row(game):
     """np.uint64[8] of the oracle game's current board (state incl. derived ep bit)."""
     return board_to_array(game.board_at(0))
+
+
+def oracle_games_parallel(net_kw, seed, sims, gid_colors, workers=None):
+    """{game id: history} of complete oracle self-play games (noise on, per-game streams as in
+    SelfPlayRunner), played on the host cores in parallel by child interpreters
+    (``python -m tests.oracle_worker``: CPU only, started as ordinary child processes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    workers = workers or max(1, min(16, (os.cpu_count() or 2) - 1, len(gid_colors)))
+    procs = []
+    for w in range(workers):
+        jobs = [dict(net=net_kw, seed=seed, sims=sims, gid=int(g), color=bool(c))
+                for g, c in gid_colors[w::workers]]
+        p = subprocess.Popen([sys.executable, "-m", "tests.oracle_worker"], cwd=root, stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, text=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        p.stdin.write(json.dumps(jobs))
+        p.stdin.close()
+        procs.append(p)
+    out = {}
+    for p in procs:
+        data = p.stdout.read()
+        if p.wait() != 0:
+            raise RuntimeError("oracle worker failed")
+        out.update({int(k): v for k, v in json.loads(data).items()})
+    return out
