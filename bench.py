@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- MCTS simulations/sec of the lockstep self-play loop on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is
-launched through torch.distributed.run, one rank per GPU.  One *step* is one lockstep
-pass of the hot path: one MCTS simulation (select -> expand S1 -> tower -> reply S2 ->
-tower -> backup) for EACH of the G games resident on the GPU, move boundaries (fresh
-tree, root priors, host compute_policy, two pushes) included whenever a game's budget of
-800 simulations completes.  ``value`` = simulations completed by all ranks / wall time of
-the K timed steps (max over ranks), state resident in HBM throughout.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the driver
+launches it through torch.distributed.run, one rank per GPU; run by hand with ``--gpus N`` and
+no WORLD_SIZE in the environment it starts the N rank processes itself (ordinary child
+processes, started before this process touches a GPU) and exits with their status.  Either way
+every rank checks ``--gpus`` against the process group's world size and the ranks exchange one
+all_reduce before anything is timed: a line with ``n_gpus: N`` was produced by N ranks.
 
-Workload (BASELINE.json metric "MCTS simulations/sec at 800 sims/move", config C3 --
-fits one GPU): 4096 games in lockstep per GPU, 800 sims/move, 10-block/128-filter
-random-init tower, fp16 MFMA trunk, all games from the standard position, Dirichlet
-noise on.  Games are independent: ranks share nothing on the hot path (weak scaling).
+One *step* is one lockstep pass of the hot path: one MCTS simulation (select -> expand S1 ->
+tower -> reply S2 -> tower -> backup) for EACH of the G games resident on the GPU, move
+boundaries (fresh tree, root priors, host compute_policy, two pushes) included whenever a
+game's budget of simulations completes.  ``value`` = simulations completed by all ranks / wall
+time of the K timed steps (max over ranks), state resident in HBM throughout.  When K is
+shorter than one move the window is placed mid-move (the trees are pre-grown un-timed), so a
+short run sees trees of representative depth instead of 800 root expansions.
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel (the 3x3
-residual-block convolution, MFMA-bound), ``roofline_tree`` for the hand-written HIP
-search kernels (HBM-bound), ``cpu_baseline`` for the reference-shaped CPU port
-(oracle/, config C1) timed on this box's host cores on rank 0 at N=1.
+Workload (BASELINE.json metric "MCTS simulations/sec at 800 sims/move", config C3 -- fits one
+GPU): 4096 games in lockstep per GPU, 800 sims/move, 10-block/128-filter random-init tower,
+fp16 MFMA trunk, all games from the standard position, Dirichlet noise on.  Games are
+independent: ranks share nothing on the hot path (weak scaling); for N > 1 the line also
+carries ``record_gather``: the RCCL all_gather of every rank's game records (C4's only
+collective), timed after the measured region.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (the fused trunk,
+MFMA-bound), ``roofline_tree`` for the hand-written HIP search kernels (HBM-bound),
+``cpu_baseline`` for the reference-shaped CPU port (oracle/, config C1) timed on this box's
+host cores on rank 0 at N=1.  ``traffic`` figures come from the tracked PMC table
+profiles/pmc_traffic.json (rocprofv3 passes of exactly the named kernel and shape); they are
+null when no pass exists for the kernel that ran.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +45,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+GAME_LENGTH_C3 = 165.5      # moves per game, 512 complete games: profiles/r01/game_length_c3net_800sims.json
 
 
 def parse():
@@ -52,8 +67,79 @@ def parse():
     return p.parse_args()
 
 
-def event_time_ms(fn, reps, stream_sync=True):
-    """Average duration of fn() on torch's current stream, HIP events around `reps` calls."""
+# ---- launching the ranks -------------------------------------------------------------------------
+def spawn_ranks(n):
+    """``--gpus n`` without a launcher: start n rank processes of this script (children, started
+    before this process has made any GPU call) and return the worst exit status."""
+    if "CRL_BENCH_DEVICE" not in os.environ and os.environ.get("CRL_BENCH_DRYRUN") != "1":
+        have = torch.cuda.device_count()                   # counting devices does not initialise one
+        if have < n:
+            print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:                              # one rank died: the others would hang in RCCL
+                    rc = rc or code
+                    for q in live:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def init_ranks(a):
+    """(rank, world, local device, dist or None): joins the process group the launcher described
+    and proves that ``--gpus`` ranks are really there."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # self-test hooks: CRL_BENCH_DEVICE pins every rank to one device (1-GPU box) and
+    # CRL_BENCH_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised anywhere
+    if "CRL_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["CRL_BENCH_DEVICE"])
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if world == 1:
+        return rank, world, local, None
+    import torch.distributed as dist
+    backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev = torch.device("cuda", local)
+    else:
+        dist.init_process_group(backend)
+        dev = torch.device("cpu")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    if dist.get_world_size() != a.gpus or t.item() != a.gpus * (a.gpus + 1) / 2:
+        raise SystemExit("bench.py: process group has %d ranks (all_reduce check %.1f), --gpus %d"
+                         % (dist.get_world_size(), t.item(), a.gpus))
+    return rank, world, local, dist
+
+
+# ---- measurement helpers ---------------------------------------------------------------------------
+def event_time_ms(fn, reps):
+    """Average duration of fn() on torch's current stream -- the stream the HIP kernels are
+    launched on (LockstepEngine binds the context to it) -- HIP events around `reps` calls."""
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     fn()
@@ -93,6 +179,28 @@ def profile_phases(run, n):
             for k, nm in enumerate(names)}
 
 
+def pmc_traffic(kernel, shape):
+    """HBM-side bytes per launch of `kernel` at `shape` from the tracked PMC table (FETCH_SIZE x 2,
+    the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE), or (None, why)."""
+    try:
+        table = json.load(open(PMC_TABLE))
+    except (OSError, ValueError):
+        return None, "no PMC table (%s)" % os.path.relpath(PMC_TABLE, ROOT)
+    for e in table.get("passes", []):
+        if e["kernel"] == kernel and e["shape"] == shape:
+            return 2.0 * e["fetch_size_kb"] * 1e3 + e["write_size_kb"] * 1e3, e["source"]
+    return None, "no PMC pass of %s at %s in %s" % (kernel, shape, os.path.relpath(PMC_TABLE, ROOT))
+
+
+def trunk_kernel_name(F, G, bits):
+    """The dispatch rule of crl_trunk_forward (csrc/api.hip), as rocprofv3 prints the kernel."""
+    if G <= 128 * (2 if F == 256 else 4):
+        return "k_trunk_gen<%d, %d, %d>" % (F, 1 if F == 256 else 2, bits)
+    if F == 128:
+        return "k_trunk128_pipe<0, %d>" % bits
+    return "k_trunk_gen<%d, %d, %d>" % (F, 2 if F == 256 else 4, bits)
+
+
 def cpu_baseline(seconds):
     """Reference-shaped CPU self-play (config C1: 1 game, 50 sims/move, tiny random-init net,
     sequential object tree, one tower call per request), bounded to ~`seconds` of CPU work."""
@@ -117,23 +225,64 @@ def cpu_baseline(seconds):
             "host_cores": os.cpu_count()}
 
 
+def time_record_gather(run, dist, max_plies):
+    """C4's one collective: every rank's game records to every rank (records.gather_blocks:
+    RCCL all_gather over xGMI).  The records are the device's own record arrays of the G games
+    resident on each rank -- what a finished wave of games hands over."""
+    import numpy as np
+    from chessrl_amd import records
+    moves, plies, res = run.engine.ctx.records()
+    t0 = time.perf_counter()
+    block = records.pack_arrays(run.game_id, moves, plies, res, run.color, max_plies)
+    pack_ms = (time.perf_counter() - t0) * 1e3
+    dist.barrier()
+    best = None
+    for _ in range(3):
+        st = {}
+        rows, counts = records.gather_blocks(block, stats=st)
+        if best is None or st["ms"] < best["ms"]:
+            best = st
+        dist.barrier()
+    assert rows.shape[0] == sum(counts) and len(np.unique(rows[:, 0].astype(np.int64) |
+                                                           (rows[:, 1].astype(np.int64) << 31))) == rows.shape[0]
+    return {"records": int(rows.shape[0]), "bytes_per_record": int(rows.shape[1] * 4),
+            "bytes_gathered_per_rank": int(best["bytes_gathered"]), "ms": best["ms"],
+            "GB_per_s_per_rank": best["bytes_gathered"] / best["ms"] / 1e6, "host_pack_ms": pack_ms,
+            "backend": best["backend"],
+            "what": "all_gather of counts + padded int32 record blocks incl. H2D/D2H staging, best of 3"}
+
+
+def dry_run(a, rank, world, dist):
+    """CRL_BENCH_DRYRUN=1 (tests, no GPU needed): the launcher / process-group / record-gather
+    control flow only.  Nothing is measured and the line says so."""
+    import numpy as np
+    from chessrl_amd import records
+    rng = np.random.default_rng(rank)
+    n = 5 + rank
+    plies = rng.integers(0, 40, n)
+    block = records.pack_arrays(rank + world * np.arange(n), rng.integers(0, 4000, (n, 64)), plies,
+                                np.full(n, 2), np.zeros(n), 64)
+    st = {}
+    rows, counts = records.gather_blocks(block, stats=st)
+    assert counts == [5 + r for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "MCTS simulations/sec at 800 sims/move", "value": None,
+                          "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "record_gather": {"records": int(rows.shape[0]), "backend": st.get("backend")}}),
+              flush=True)
+
+
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # self-test hooks (1-GPU box): CRL_BENCH_DEVICE pins every rank to one device and
-    # CRL_BENCH_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
-    if "CRL_BENCH_DEVICE" in os.environ:
-        local = int(os.environ["CRL_BENCH_DEVICE"])
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    rank, world, local, dist = init_ranks(a)
+    if os.environ.get("CRL_BENCH_DRYRUN") == "1":
+        dry_run(a, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local)
@@ -144,8 +293,9 @@ def main():
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
     model = ChessModel(blocks=a.blocks, filters=a.filters, device="cuda:%d" % local, dtype=tdt,
                        seed=a.seed, fused=not a.no_fused)
+    max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
-                         device=local, use_graph=not a.no_graph, max_plies=2048)
+                         device=local, use_graph=not a.no_graph, max_plies=max_plies)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,8 +303,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    # a window shorter than a move is centred on the middle of a move (trees pre-grown un-timed)
+    pre = 0
+    if a.steps < a.sims:
+        pre = max(0, (a.sims - a.steps) // 2 - a.warmup)
+    for _ in range(pre + a.warmup):
         run.step()
+    window_start = run._sims_in_move or 0
+    moves0 = run.moves_played
     c0 = run.engine.ctx.counters()
     barrier()
     t0 = time.perf_counter()
@@ -175,8 +331,8 @@ def main():
         total_sims, max_dt = s[0].item(), m[1].item()
     else:
         total_sims, max_dt = float(sims), dt
+    gather = time_record_gather(run, dist, max_plies) if world > 1 else None
 
-    out = None
     if rank == 0:
         G, F, B = a.games, a.filters, a.blocks
         eng = run.engine
@@ -184,23 +340,25 @@ def main():
         nodes = max(1, d["nodes"])
         depth = d["depth_sum"] / max(1, d["sims"])
         branch = d["branch_sum"] / nodes
+        shape = "%d boards, %d blocks x %d filters" % (G, B, F)
         # ---- dominant kernel (MFMA-bound) ----------------------------------------------------
         tower_ms = event_time_ms(lambda: model.forward_into(eng.planes_s2, eng.pol_s2, eng.val_s2), 20)
         tower_flops = 2.0 * model.macs_per_eval() * G
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         if model.fused:
-            # crl_tower::k_trunk128 -- the hand-written fused trunk: ONE launch per tower forward.
-            # Algorithmic FLOPs per launch = 2 x (stem 73152 F + blocks 1152 F^2 B + head convs
-            # 192 F) MACs per board x G boards.
+            # the hand-written fused trunk: ONE launch per tower forward.  Algorithmic FLOPs per
+            # launch = 2 x (stem 73152 F + blocks 1152 F^2 B + head convs 192 F) MACs per board
+            #  x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (
-                # the dispatch rule of crl_trunk_forward (csrc/api.hip)
-                ("k_trunk_gen<%d, %d, %d>" % (F, (1 if F == 256 else 2), eng.bitplanes)
-                 if G <= 128 * (2 if F == 256 else 4)
-                 else "k_trunk128_pipe<0, %d>" % eng.bitplanes if F == 128
-                 else "k_trunk_gen<%d, %d, %d>" % (F, 2 if F == 256 else 4, eng.bitplanes)),
-                B, G)
+            kern = trunk_kernel_name(F, G, int(eng.bitplanes))
+            k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (kern, B, G)
+            traffic, traffic_src = pmc_traffic(kern, shape)
+            # what one launch must move: the encoder's planes as handed over (1 KiB of plane
+            # bitboards per board, or 16 KiB of fp16 planes), the folded fp16 weights once, the
+            # head activations (192 floats per board)
+            plane_in = 1024 if eng.bitplanes else 64 * 128 * 2
+            alg_bytes = G * plane_in + (9 * 128 * F + 2 * B * 9 * F * F) * 2 + G * 192 * 4
         else:
             # PyTorch-ROCm tower: the FxF 3x3 residual-block convolution.  bias=None: exactly ONE
             # kernel per call (MIOpen igemm_fwd_gtcx35_nhwc_*), comparable with rocprofv3 --stats
@@ -209,14 +367,11 @@ def main():
             k_ms = event_time_ms(lambda: torch.nn.functional.conv2d(x, conv.weight, None, padding=1), 50)
             k_flops = 2.0 * 9 * F * F * 64 * G
             k_name = "3x3 conv %d->%d, batch %d x 8x8 (PyTorch-ROCm / MIOpen igemm)" % (F, F, G)
-        # traffic: rocprofv3 PMC passes of this kernel at this exact shape (profiles/r01/
-        # pmc_trunk_kernel.md): FETCH_SIZE 129 858 KB x 2 (gfx950 correction) + WRITE_SIZE 3 072 KB
-        traffic = 2 * 129858e3 + 3072e3 if (model.fused and (G, F, B) == (4096, 128, 10)) else None
+            traffic, traffic_src, alg_bytes = None, "not profiled", None
         roof = {"bound": "mfma", "kernel": k_name,
                 "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
-                "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic,
-                "algorithmic_bytes": (G * 64 * 128 * 2 + 9 * 128 * F * 2 + 2 * B * 9 * F * F * 2 + G * 192 * 4)
-                if model.fused else None,
+                "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": alg_bytes,
                 "launch_ms": k_ms, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}
@@ -228,14 +383,16 @@ def main():
         tree_bytes = 2400.0 + 20.0 * depth * branch + 2 * plane_bytes
         ph = profile_phases(run, 16)
         tree_ms = ph["select_expand"] + ph["reply"]
+        t_traffic, t_src = pmc_traffic("k_select_expand + k_reply",
+                                       "%d games, %s planes" % (G, "bit" if eng.bitplanes else "fp16"))
         tree = {"bound": "hbm", "kernel": "k_select_expand + k_reply (one simulation x %d games)" % G,
                 "achieved": tree_bytes * G / tree_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS,
-                # PMC passes of both kernels at 4096 games (profiles/r01/pmc_tree_kernels.md): bytes/step
-                "traffic": ((2 * (16054e3 + 6415e3) + 42729e3 + 7731e3) if eng.bitplanes else
-                            (2 * (27370e3 + 6435e3) + 102267e3 + 69172e3)) if G == 4096 else None,
+                "traffic": t_traffic, "traffic_source": t_src,
                 "launch_ms": tree_ms, "phase_ms": ph, "bytes_per_sim": tree_bytes,
                 "mean_depth": depth, "mean_branch": branch}
+        cfg_name = {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
+                    (4096, 800, 20, 256): "C5 per-GPU shard"}.get((G, a.sims, B, F), "custom")
         out = {
             "metric": "MCTS simulations/sec at 800 sims/move", "value": total_sims / max_dt,
             "unit": "simulations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -243,26 +400,31 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: %d self-play games in lockstep per GPU, %d sims/move, "
                                    "%d-block/%d-filter random-init tower, standard start position, "
-                                   "Dirichlet noise on" % (
-                                       {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
-                                        (4096, 800, 20, 256): "C5 per-GPU shard"}.get(
-                                           (G, a.sims, B, F), "custom"), G, a.sims, B, F),
+                                   "Dirichlet noise on" % (cfg_name, G, a.sims, B, F),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
-                       "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused), "parallelism": "games sharded, no collective on the hot path"},
+                       "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
+                       "tower_precision": getattr(model, "precision", a.dtype),
+                       "parallelism": "games sharded, no collective on the hot path"},
+            "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,
+                       "move_boundaries_inside": (run.moves_played - moves0) // max(1, G),
+                       "note": "a window shorter than one move is centred mid-move"},
             "moves_per_sec": total_sims / max_dt / a.sims,
             # games/hour: a random-init 10x128 net at 800 sims/move plays 165.5 moves (331 plies) per
-            # game on average (512 complete games, profiles/r01/game_length_c3net_800sims.json;
-            # 190 moves at 50 sims/move); steady state with refill = moves/s / moves per game
-            "self_play_games_per_hour_est": total_sims / max_dt / a.sims / 165.5 * 3600.0,
+            # game on average (512 complete games, profiles/r01/game_length_c3net_800sims.json);
+            # steady state with refill = moves/s / moves per game.  Only stated for that config.
+            "self_play_games_per_hour_est": (total_sims / max_dt / a.sims / GAME_LENGTH_C3 * 3600.0
+                                             if (a.sims, B, F) == (800, 10, 128) else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
             "roofline": roof, "roofline_tree": tree,
         }
+        if gather is not None:
+            out["record_gather"] = gather
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()            # rank 0 is still profiling its phases: nobody tears NCCL down early
+        dist.barrier()            # rank 0 is still profiling its phases: nobody tears RCCL down early
     run.close()
     if world > 1:
         dist.destroy_process_group()

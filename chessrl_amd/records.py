@@ -53,58 +53,91 @@ def loads(text):
     return out
 
 
+def row_width(max_plies):
+    return HEADER + (max_plies + 1) // 2
+
+
+def pack_arrays(game_ids, moves, plies, results, colors, max_plies):
+    """The wire block straight from the device's record arrays (``crl_records``): int32
+    [n, HEADER + ceil(max_plies/2)], two u16 moves per int32.  ``results`` uses 2 for None."""
+    game_ids = np.asarray(game_ids, dtype=np.int64)
+    plies = np.asarray(plies, dtype=np.int64)
+    n, w = len(game_ids), row_width(max_plies)
+    if n and plies.max() > max_plies:
+        raise ValueError("record longer than max_plies")
+    out = np.zeros((n, w), dtype=np.int32)
+    out[:, 0] = game_ids & 0x7FFFFFFF
+    out[:, 1] = game_ids >> 31
+    out[:, 2] = plies
+    out[:, 3] = np.asarray(results, dtype=np.int64)
+    out[:, 4] = np.asarray(colors, dtype=np.int64)
+    mv = np.zeros((n, 2 * (w - HEADER)), dtype=np.uint16)
+    src = (np.asarray(moves, dtype=np.uint16).reshape(n, -1) if n else np.zeros((0, 0), np.uint16))[:, :max_plies]
+    mv[:, :src.shape[1]] = np.where(np.arange(src.shape[1])[None, :] < plies[:, None], src, 0)
+    out[:, HEADER:] = mv.view(np.int32)
+    return out
+
+
 def pack(records, max_plies):
-    """records -> int32 [n, HEADER + ceil(max_plies/2)] (two u16 moves per int32)."""
-    w = HEADER + (max_plies + 1) // 2
-    out = np.zeros((len(records), w), dtype=np.int32)
+    """records -> the wire block (see ``pack_arrays``)."""
+    n = len(records)
+    moves = np.zeros((n, max_plies), dtype=np.uint16)
     for i, r in enumerate(records):
         if len(r.moves) > max_plies:
             raise ValueError("record longer than max_plies")
-        out[i, 0] = r.game_id & 0x7FFFFFFF
-        out[i, 1] = r.game_id >> 31
-        out[i, 2] = len(r.moves)
-        out[i, 3] = 2 if r.result is None else r.result
-        out[i, 4] = int(r.player_color)
-        mv = np.zeros(2 * (w - HEADER), dtype=np.uint16)
-        mv[:len(r.moves)] = r.moves
-        out[i, HEADER:] = mv.view(np.int32)
-    return out
+        moves[i, :len(r.moves)] = r.moves
+    return pack_arrays([r.game_id for r in records], moves, [len(r.moves) for r in records],
+                       [2 if r.result is None else r.result for r in records],
+                       [int(r.player_color) for r in records], max_plies)
 
 
 def unpack(rows):
     rows = np.ascontiguousarray(rows, dtype=np.int32)
-    out = []
-    for row in rows:
-        n = int(row[2])
-        mv = row[HEADER:].copy().view(np.uint16)[:n]
-        res = None if row[3] == 2 else int(row[3])
-        out.append(GameRecord(int(row[0]) | (int(row[1]) << 31), mv, res, bool(row[4])))
-    return out
+    mv = rows[:, HEADER:].copy().view(np.uint16) if len(rows) else np.zeros((0, 0), np.uint16)
+    gid = rows[:, 0].astype(np.int64) | (rows[:, 1].astype(np.int64) << 31)
+    return [GameRecord(int(gid[i]), mv[i, :int(rows[i, 2])], None if rows[i, 3] == 2 else int(rows[i, 3]),
+                       bool(rows[i, 4])) for i in range(len(rows))]
 
 
-def gather_records(records, max_plies, device=None):
-    """All ranks' finished records on every rank, ordered by game id.
-
-    One all_gather of the per-rank counts and one of the padded record block.  Without an
-    initialised process group (single GPU) it is the identity.
-    """
+def gather_blocks(block, device=None, stats=None):
+    """Every rank's wire block on every rank: (rows of all ranks concatenated in rank order,
+    per-rank row counts).  Two collectives -- the counts, then the blocks padded to the largest
+    count -- and ONE device-to-host copy each; RCCL over xGMI with the ``nccl`` backend, ``gloo``
+    in the CPU tests.  ``stats`` (a dict) receives the bytes moved and the wall time of the
+    exchange (host staging included)."""
+    import time
     import torch
+    import torch.distributed as dist
+    block = np.ascontiguousarray(block, dtype=np.int32)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if stats is not None:
+            stats.update(world=1, rows=int(block.shape[0]), bytes_gathered=0, ms=0.0)
+        return block, [block.shape[0]]
+    world = dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    dev = device if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
+    t0 = time.perf_counter()
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([block.shape[0]], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in counts.cpu().tolist()]
+    nmax, w = max(counts), block.shape[1]
+    padded = torch.zeros((nmax, w), dtype=torch.int32, device=dev)
+    padded[:block.shape[0]] = torch.from_numpy(block).to(dev)
+    allb = torch.empty((world * nmax, w), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(allb, padded)
+    host = allb.cpu().numpy().reshape(world, nmax, w)
+    if stats is not None:
+        stats.update(world=world, rows=sum(counts), bytes_gathered=world * nmax * w * 4,
+                     ms=(time.perf_counter() - t0) * 1e3, backend=dist.get_backend())
+    return np.concatenate([host[r, :counts[r]] for r in range(world)], axis=0), counts
+
+
+def gather_records(records, max_plies, device=None, stats=None):
+    """All ranks' finished records on every rank, ordered by game id (identity without a
+    process group)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sorted(records, key=lambda r: r.game_id)
-    world = dist.get_world_size()
-    dev = device if device is not None else (
-        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
-        else torch.device("cpu"))
-    mine = torch.from_numpy(pack(records, max_plies)).to(dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev))
-    nmax = max(int(c.item()) for c in counts)
-    padded = torch.zeros((nmax, mine.shape[1]), dtype=torch.int32, device=dev)
-    padded[:mine.shape[0]] = mine
-    blocks = [torch.zeros_like(padded) for _ in range(world)]
-    dist.all_gather(blocks, padded)
-    out = []
-    for c, b in zip(counts, blocks):
-        out.extend(unpack(b[:int(c.item())].cpu().numpy()))
-    return sorted(out, key=lambda r: r.game_id)
+    rows, _ = gather_blocks(pack(records, max_plies), device=device, stats=stats)
+    return sorted(unpack(rows), key=lambda r: r.game_id)

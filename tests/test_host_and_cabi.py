@@ -199,3 +199,28 @@ def test_bench_refuses_to_run_without_a_gpu():
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0
     assert "MI355X" in (r.stderr + r.stdout) and "{" not in r.stdout
+
+
+def test_bench_gpus_2_starts_two_ranks_and_checks_the_world(tmp_path):
+    """``bench.py --gpus 2`` without a launcher starts two rank processes itself; the ranks join
+    one process group (gloo here), prove the world size with an all_reduce and run the record
+    gather.  CRL_BENCH_DRYRUN=1 stops before the GPU workload (nothing is measured: value null)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CRL_BENCH_DRYRUN="1", CRL_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None
+    assert out["record_gather"] == {"records": 5 + 6, "backend": "gloo"}
+    # a launcher that started a different number of ranks than --gpus says is refused
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29400")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "{" not in r.stdout
