@@ -5,6 +5,7 @@ is visible, every entry point raises.  ``build()`` compiles the library in-tree
 with hipcc for gfx950 (works without a GPU: hipcc cross-compiles).
 """
 import ctypes
+import hashlib
 import os
 import subprocess
 
@@ -12,10 +13,28 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
+_CSRC = os.path.join(_PKG, "csrc")
 SO_PATH = os.path.join(_PKG, "libchessrl_hip.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("api.hip", "board.hpp", "movegen.hpp", "state.hpp", "search.hpp", "tower.hpp", "tower_pipe.hpp", "tower_gen.hpp")]
+# the tuning library (tools/trunk_bench.py): the product plus the first-build and timing-only trunk
+# kernels (-DCRL_TUNING); never built by build()/__graft_entry__ and never loaded by the package
+SO_TUNING_PATH = os.path.join(_PKG, "libchessrl_hip_tuning.so")
 HEADER = os.path.join(_ROOT, "include", "chessrl_hip.h")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def sources():
+    """Every file the library is compiled from (all of csrc/ and the public header)."""
+    files = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    return files + [HEADER]
+
+
+def source_hash(extra=()):
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + list(extra)).encode())
+    for f in sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
 
 MAX_MOVES = 256
 N_LABELS = 1968
@@ -32,7 +51,7 @@ SYMBOLS = [
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
-    "crl_trunk_forward_bitplanes",
+    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -41,42 +60,59 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> chessrl_amd/libchessrl_hip.so (in-tree)."""
-    srcs = [s for s in SOURCES + [HEADER] if os.path.exists(s)]
-    if not force and os.path.exists(SO_PATH):
-        if not srcs or all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs):
-            return SO_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-shared", "-o", SO_PATH, SOURCES[0]]
+def _stamp(so):
+    return so + ".srchash"
+
+
+def is_stale(so=SO_PATH, extra=()):
+    """True when `so` is missing or was not compiled from the sources as they are now (the build
+    leaves the sources' sha256 next to the library)."""
+    if not (os.path.exists(so) and os.path.exists(_stamp(so))):
+        return True
+    return open(_stamp(so)).read().strip() != source_hash(extra)
+
+
+def build(force=False, verbose=False, tuning=False):
+    """hipcc --offload-arch=gfx950 -> chessrl_amd/libchessrl_hip.so (in-tree; works without a GPU).
+    Recompiles whenever any file of csrc/ or the header changed since the library was built."""
+    so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
+    if not force and not is_stale(so, extra):
+        return so
+    cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", so, os.path.join(_CSRC, "api.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO_PATH
+    with open(_stamp(so), "w") as f:
+        f.write(source_hash(extra) + "\n")
+    return so
 
 
 _lib = None
 
 
 def lib():
-    """Load the shared library (never builds implicitly on a GPU box without hipcc)."""
+    """Load the shared library, compiling it first when it is missing or older than its sources
+    (``CRL_TUNING_LIB=1``: the tuning library instead, tools only).  No CPU fallback: without a
+    loadable library this raises."""
     global _lib
     if _lib is not None:
         return _lib
     # torch bundles its own libamdhip64; it must be the copy this process binds, or the tower and
     # the search kernels would sit on two HIP runtimes (and the second one sees no device)
     import torch  # noqa: F401
-    if not os.path.exists(SO_PATH):
+    tuning = os.environ.get("CRL_TUNING_LIB") == "1"
+    so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
+    if is_stale(so, extra):
         try:
-            build()
+            build(tuning=tuning)
         except Exception as e:  # pragma: no cover
             raise HipLibraryError(
-                "libchessrl_hip.so is missing and could not be built with hipcc (%s); "
-                "the HIP path has no CPU fallback" % e)
+                "%s is missing or older than csrc/ and could not be rebuilt with hipcc (%s); "
+                "the HIP path has no CPU fallback" % (os.path.basename(so), e))
     try:
-        L = ctypes.CDLL(SO_PATH)
+        L = ctypes.CDLL(so)
     except OSError as e:
-        raise HipLibraryError("cannot load %s: %s" % (SO_PATH, e))
+        raise HipLibraryError("cannot load %s: %s" % (so, e))
     vp, i32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
     L.crl_create.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, u32]
     L.crl_destroy.argtypes = [vp]
@@ -113,6 +149,7 @@ def lib():
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_set_plane_format.argtypes = [vp, i32]
+    L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:

@@ -88,19 +88,20 @@ class Agent(Player):
         pass
 
     def train(self, dataset, epochs=1, logdir=None, batch_size=1, validation_split=0):
-        """agent.py:64-89: train the model on recorded games."""
+        """Fit the model on recorded games (agent.py:64-89).  The last
+        ``validation_split`` fraction of the games is held out for validation; training batches
+        are flipped at random with probability 0.1.  Nothing happens on an empty dataset."""
         from .dataset import DatasetGame
-        from . import netencoder
-        if len(dataset) <= 0:
+        n = len(dataset)
+        if n == 0:
             return None
+        held_out = int(validation_split * n) if validation_split > 0 else 0
+        val_gen = None
         if validation_split > 0:
-            split_point = len(dataset) - int(validation_split * len(dataset))
-            games_train = DatasetGame(dataset[:split_point])
-            val_gen = netencoder.DataGameSequence(DatasetGame(dataset[split_point:]), batch_size=batch_size)
-        else:
-            games_train, val_gen = dataset, None
-        train_gen = netencoder.DataGameSequence(games_train, batch_size=batch_size, random_flips=.1)
-        return self.model.train_generator(train_gen, epochs=epochs, logdir=logdir, val_gen=val_gen)
+            val_gen = netencoder.DataGameSequence(DatasetGame(dataset[n - held_out:]), batch_size=batch_size)
+            dataset = DatasetGame(dataset[:n - held_out])
+        fit_gen = netencoder.DataGameSequence(dataset, batch_size=batch_size, random_flips=.1)
+        return self.model.train_generator(fit_gen, epochs=epochs, logdir=logdir, val_gen=val_gen)
 
     def save(self, path):
         self.model.save_weights(path)

@@ -2,15 +2,20 @@
 // C-ABI declared in include/chessrl_hip.h.  gfx950 only; no torch types cross this boundary.
 #include "../../include/chessrl_hip.h"
 #include "search.hpp"
+#ifdef CRL_TUNING
 #include "tower.hpp"
+#endif
 #include "tower_pipe.hpp"
 #include "tower_gen.hpp"
 #include "train_ops.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace crl;
@@ -517,6 +522,41 @@ int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const voi
                              n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
+// small batches run half-size workgroups (see below); crl_trunk_set_small_batch turns that off
+static std::atomic<int> g_small_batch{1};
+
+int crl_trunk_set_small_batch(int enabled)
+{
+    g_small_batch.store(enabled ? 1 : 0);
+    return CRL_OK;
+}
+
+#ifdef CRL_TUNING
+// Tuning library only: CRL_TRUNK_VARIANT selects first-build / timing-only builds of the 128-filter
+// kernel (tools/trunk_bench.py; the ladder in profiles/r01/pmc_trunk_kernel.md).  Read once.
+static int tuning_variant()
+{
+    static const int v = [] { const char *e = getenv("CRL_TRUNK_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#endif
+
+// opt in to > 64 KiB of dynamic LDS once per (device, kernel)
+static hipError_t allow_big_lds(const void *kern, int lds_bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void *>> ready;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &k : ready)
+        if (k.first == dev && k.second == kern) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) ready.push_back({ dev, kern });
+    return e;
+}
+
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, bool bits,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
@@ -536,7 +576,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     int boards_per_wg = crl_tower::BOARDS_PER_WG;
     // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
     // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
-    const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && !getenv("CRL_TRUNK_NO_SMALL");
+    const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
 #define CRL_GEN(F_, NB_)                                                                        \
     do {                                                                                         \
         kern = bits ? crl_tower::k_trunk_gen<F_, NB_, 1> : crl_tower::k_trunk_gen<F_, NB_, 0>;   \
@@ -549,11 +589,11 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4);
     } else if (small) {
         CRL_GEN(128, 2);
-    } else if (const char *ev = bits ? nullptr : getenv("CRL_TRUNK_VARIANT")) {
-        // tuning / timing-only builds of the 128-filter kernel (tools/trunk_bench.py; the ladder in
-        // profiles/r01/pmc_trunk_kernel.md).  Unset or 0 = production.
+    }
+#ifdef CRL_TUNING
+    else if (!bits && tuning_variant() != 0) {
         const int first = crl_tower::LDS_BYTES;        // LDS size of the first-build kernels
-        switch (atoi(ev)) {
+        switch (tuning_variant()) {
         case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = first; break;    // unpipelined baseline
         case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = first; break;     // + s_setprio
         case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = first; break;     // all reads up front
@@ -576,17 +616,10 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         default: break;
         }
     }
+#endif
 #undef CRL_GEN
-    // opt in to > 64 KiB of dynamic LDS once per kernel
-    static std::vector<const void *> lds_ready;
-    bool seen = false;
-    for (const void *k : lds_ready) seen = seen || k == (const void *)kern;
-    if (!seen) {
-        hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            lds_bytes);
-        if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
-        lds_ready.push_back((const void *)kern);
-    }
+    hipError_t ea = allow_big_lds((const void *)kern, lds_bytes);
+    if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
     hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),
                        lds_bytes, (hipStream_t)hip_stream,
                        (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,

@@ -1,9 +1,9 @@
 // tower_pipe.hpp -- PRODUCTION build of the fused residual trunk (128 filters) for gfx950.
 //
-// Same math, weight tile format and wave tiling as tower.hpp (read its header first: LDS-resident
-// boards, fp32 residual stream in registers, LDS-DMA weight ring, transposed product, in-place
-// epilogue); results are bit-identical to it.  tower.hpp is the first, straightforward build and is
-// kept as the baseline of the ladder in profiles/r01/pmc_trunk_kernel.md.  Its rocprofv3 counters
+// Design: tower_common.hpp (read its header first: LDS-resident boards, fp32 residual stream in
+// registers, LDS-DMA weight ring, transposed product, in-place epilogue).  tower.hpp is the first,
+// straightforward build of it (tuning library only), the baseline of the ladder in
+// profiles/r01/pmc_trunk_kernel.md; results are bit-identical to it.  Its rocprofv3 counters
 // at the C3 shape showed the matrix pipe 51 % busy, waves parked in s_waitcnt/s_barrier 38 % of
 // their cycles, ~4 VALU instructions per MFMA, the LDS array 39 % busy with 18 % conflicts.  What
 // this build changes, in the order it paid:
@@ -30,7 +30,7 @@
 // with changing operands (1.5-1.6 PFLOP/s on this chip).
 #pragma once
 #include <type_traits>
-#include "tower.hpp"
+#include "tower_common.hpp"
 
 namespace crl_tower {
 
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                                                            const float *__restrict__ head_b,
                                                            float *__restrict__ head_out)
 {
+#ifndef CRL_TUNING
+    static_assert(DIAG == 0, "timing-only variants exist in the tuning library only");
+#endif
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
     const int lds_base = (int)(size_t)lds;              // LDS byte address of the dynamic array

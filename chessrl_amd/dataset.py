@@ -1,82 +1,95 @@
-"""``DatasetGame`` -- host mirror of the reference's game-record container.
+"""``DatasetGame`` -- the reference's container of recorded games.
 
-Same surface as /root/reference/src/chessrl/dataset.py:6-97:
-a list of ``Game`` objects, JSON (de)serialisation of ``Game.get_history()`` dicts
-(``{moves, result, player_color, date}``), ``augment_game`` (one training sample per move).
-Games are the HIP-backed ``chessrl_amd.game.Game``; ``loads`` replays the recorded moves
-through the rules kernels exactly like the reference replays them through python-chess.
-``records.GameRecord`` is the slot-free form the lockstep runner produces;
-``from_records`` converts.
+Drop-in for /root/reference/src/chessrl/dataset.py:6-97: holds games, reads and writes the JSON
+list of ``Game.get_history()`` dicts (``{moves, result, player_color, date}``) and expands a game
+into one training sample per move (``augment_game``).  Two kinds of entries are accepted
+wherever a game is expected, because both answer ``get_history()``: the HIP-backed
+``chessrl_amd.game.Game`` (one device slot each) and the slot-free ``records.GameRecord`` the
+lockstep runner emits.  Moves read from JSON are replayed through the rules kernels, i.e.
+checked, like the reference replays them through python-chess.
 """
 import json
 
-from . import game
+from . import game as game_mod
+
+
+def _replayed(moves, date, player_color):
+    g = game_mod.Game(date=date, player_color=player_color)
+    for uci in moves:
+        g.move(uci)
+    return g
+
+
+def _histories(entries):
+    return [e.get_history() for e in entries]
 
 
 class DatasetGame(object):
+
     def __init__(self, games=None):
-        self.games = [] if games is None else games
+        self.games = games if games is not None else []
 
+    # ---- samples -------------------------------------------------------------------------------
     def augment_game(self, game_base):
-        """dataset.py:21-43: for the N moves of a game, N (state, next_move, result) samples."""
-        hist = game_base.get_history()
-        augmented = []
-        g = game.Game(date=hist["date"], player_color=hist["player_color"])
-        for m in hist["moves"]:
-            augmented.append({"game": g, "next_move": m, "result": hist["result"]})
-            g = g.get_copy()
-            g.move(m)
-        return augmented
+        """One ``{game, next_move, result}`` sample per recorded move: the position before the
+        move, the move played there and the game's final result (dataset.py:21-43)."""
+        h = game_base.get_history()
+        samples = []
+        position = game_mod.Game(date=h["date"], player_color=h["player_color"])
+        for uci in h["moves"]:
+            samples.append(dict(game=position, next_move=uci, result=h["result"]))
+            position = position.get_copy()
+            position.move(uci)
+        return samples
 
-    def load(self, path, slot_free=False):
-        with open(path, "r") as f:
-            self.loads(f.read(), slot_free=slot_free)
-
+    # ---- JSON ------------------------------------------------------------------------------------
     def loads(self, string, slot_free=False):
-        """dataset.py:50-57.  ``slot_free=True`` keeps the games as ``GameRecord``s (no device
-        slot per game: training sets larger than the 4096-slot ``Game`` arena); the moves are then
-        replayed -- and checked -- on the device when a batch is built."""
+        """Append the games of a JSON text; games without moves are dropped (dataset.py:50-57).
+        ``slot_free=True`` keeps them as ``GameRecord``s -- no device slot per game, for sets
+        larger than the ``Game`` arena; their moves are checked when a training batch is built."""
         if slot_free:
             from . import records
-            self.games.extend(r for r in records.loads(string) if len(r) > 0)
+            self.games += [r for r in records.loads(string) if len(r)]
             return
         for item in json.loads(string):
-            g = game.Game(date=item["date"], player_color=item["player_color"])
-            if len(item["moves"]) > 0:
-                for m in item["moves"]:
-                    g.move(m)
-                self.games.append(g)
+            if item["moves"]:
+                self.games.append(_replayed(item["moves"], item["date"], item["player_color"]))
 
-    def from_records(self, records):
-        """Finished ``GameRecord``s of the lockstep runner -> ``Game`` objects."""
-        for r in records:
-            g = game.Game(date=r.date, player_color=r.player_color)
-            for m in r.get_history()["moves"]:
-                g.move(m)
-            self.games.append(g)
-        return self
+    def load(self, path, slot_free=False):
+        with open(path) as f:
+            self.loads(f.read(), slot_free=slot_free)
 
     def save(self, path):
-        existing = DatasetGame()
+        """Write the file's previous games followed by this dataset's (dataset.py:59-70)."""
+        before = DatasetGame()
         try:
-            existing.load(path)
+            before.load(path)
         except FileNotFoundError:
             pass
         with open(path, "w") as f:
-            json.dump([x.get_history() for x in existing.games + self.games], f)
-
-    def append(self, other):
-        if isinstance(other, game.Game):
-            self.games.append(other)
-        elif isinstance(other, DatasetGame):
-            self.games.extend(other.games)
+            json.dump(_histories(before.games) + _histories(self.games), f)
 
     def __str__(self):
-        return json.dumps([x.get_history() for x in self.games])
+        return json.dumps(_histories(self.games))
+
+    # ---- container ----------------------------------------------------------------------------------
+    def from_records(self, recs):
+        """``GameRecord``s -> ``Game`` objects (each takes a device slot)."""
+        self.games += [_replayed(r.get_history()["moves"], r.date, r.player_color) for r in recs]
+        return self
+
+    def append(self, other):
+        """A single game or every game of another dataset."""
+        if isinstance(other, DatasetGame):
+            self.games.extend(other.games)
+        elif isinstance(other, game_mod.Game):
+            self.games.append(other)
 
     def __add__(self, other):
         self.append(other)
         return self
+
+    __iadd__ = __add__
 
     def __len__(self):
         return len(self.games)

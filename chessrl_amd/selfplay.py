@@ -30,15 +30,12 @@ log = logging.getLogger("chessrl_amd.selfplay")
 
 
 def get_model_path(directory):
-    """Newest ``model-<v>.npz`` / ``model-<v>.h5`` of a directory (selfplay.py:33-56; a fresh
-    directory gets ``model-0.npz``, a directory of Keras ``.h5`` files keeps using ``.h5``)."""
-    path = directory + "/model-0.npz"
-    models = [f for f in os.listdir(directory) if f.endswith(("npz", "h5"))]
-    if len(models) > 0:
-        max_v = max([m.split("-")[1] for m in models])
-        m = [model for model in models if model.endswith(max_v)][0]
-        path = directory + "/" + m
-    return path
+    """Weights file a run continues from (selfplay.py:33-56): among the ``model-<v>.npz`` /
+    ``model-<v>.h5`` files of ``directory`` the one whose ``<v>.<ext>`` part compares greatest AS A
+    STRING (the reference's rule: "9" beats "10"); ``model-0.npz`` when there is none yet."""
+    found = [name for name in os.listdir(directory) if name.endswith((".npz", ".h5"))]
+    newest = max(found, key=lambda name: name.split("-")[1]) if found else "model-0.npz"
+    return os.path.join(directory, newest)
 
 
 def play_game(agent, max_iters=900):

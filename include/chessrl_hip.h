@@ -197,6 +197,11 @@ int  crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_
                                  int n_boards, int n_blocks, const void *dev_head_w_f32,
                                  const void *dev_head_b_f32, void *dev_head_out_f32);
 
+/* Batches of at most 512 boards (256 at 256 filters) give at most half of the 256 CUs a
+ * workgroup; they run the same kernels with half the boards per workgroup and twice the
+ * workgroups (identical trunk bits).  enabled = 0 turns that off process-wide (default 1). */
+int  crl_trunk_set_small_batch(int enabled);
+
 /* ---- training step (model.py:83-99 fit_generator) --------------------
  * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'
  * convolution on the 8x8 board is the GEMM [B*64, 9*C] x [9*C, Cout] over NHWC activations, and these

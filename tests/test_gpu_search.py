@@ -298,11 +298,12 @@ def test_fused_trunk_matches_pytorch_trunk_activations(filters, n_boards):
     assert heads.shape == (n_boards, 192) and (heads >= 0).all()
     if n_boards == 8:
         # both geometries accumulate every output in the same order: identical trunk bits
-        os.environ["CRL_TRUNK_NO_SMALL"] = "1"
+        from chessrl_amd import _lib
+        _lib.lib().crl_trunk_set_small_batch(0)
         try:
             trunk_big, heads_big = model._run_fused(planes, want_trunk=True)
         finally:
-            del os.environ["CRL_TRUNK_NO_SMALL"]
+            _lib.lib().crl_trunk_set_small_batch(1)
         assert torch.equal(trunk, trunk_big)
         assert (heads - heads_big).abs().max().item() <= 1e-5 * max(1.0, heads.abs().max().item())
 

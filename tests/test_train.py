@@ -11,6 +11,8 @@ its policy / value terms); gradients 5e-3
 of the tensor's max |g| (GPU GEMMs vs CPU; batch-statistics BN backward is ill-conditioned); BN moving statistics 1e-5; one Adam step from
 IDENTICAL gradients 1e-7.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -291,10 +293,13 @@ def test_agent_train_on_a_self_played_game_updates_the_search_path(tmp_path):
 
 
 @pytest.mark.gpu
-def test_supervised_cli_trains_on_a_json_dataset(tmp_path):
-    """supervised.py:37-62: DatasetGame JSON -> Agent.train(validation_split=0.25, batch_size) -> save."""
+def test_agent_train_on_a_json_dataset_with_validation_split(tmp_path):
+    """agent.py:64-89 on a DatasetGame JSON kept slot-free: the last quarter of the games is held
+    out, training continues from saved weights picked up by get_model_path."""
     import json
-    from chessrl_amd import supervised
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.dataset import DatasetGame
+    from chessrl_amd.selfplay import get_model_path
     games = []
     for s in range(8):
         g = _random_game(50 + s, 20 + 3 * s)
@@ -304,14 +309,25 @@ def test_supervised_cli_trains_on_a_json_dataset(tmp_path):
     data = tmp_path / "gameplays.json"
     data.write_text(json.dumps(games))
     mdir = str(tmp_path / "model")
+    os.makedirs(mdir)
+    ds = DatasetGame()
+    ds.load(str(data), slot_free=True)
+    assert len(ds) == 8
+    path = get_model_path(mdir)
+    assert path.endswith("model-0.npz")
     np.random.seed(0)
-    hist = supervised.train(mdir, str(data), epochs=2, batch_size=2, blocks=1, filters=64)
+    agent = Agent(True, blocks=1, filters=64)
+    hist = agent.train(ds, logdir=mdir, epochs=2, batch_size=2, validation_split=0.25)
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) and np.isfinite(h["val_loss"]) for h in hist)
     assert hist[1]["loss"] < hist[0]["loss"]
-    w0 = dict(np.load(mdir + "/model-0.npz"))
-    supervised.main([mdir, str(data), "--bs", "3"])           # picks model-0.npz up and continues
-    w1 = dict(np.load(mdir + "/model-0.npz"))
+    agent.save(path)
+    w0 = dict(np.load(path))
+    again = Agent(True, weights=get_model_path(mdir))           # picks model-0.npz up and continues
+    again.train(ds, epochs=1, batch_size=3, validation_split=0.25)
+    again.save(path)
+    w1 = dict(np.load(path))
     assert int(w1["meta.filters"]) == 64 and np.abs(w1["stem.kernel"] - w0["stem.kernel"]).max() > 0
+    assert Agent(True, blocks=1, filters=64).train(DatasetGame()) is None
 
 
 @pytest.mark.gpu
