@@ -31,6 +31,7 @@ profiles/pmc_traffic.json (rocprofv3 passes of exactly the named kernel and shap
 null when no pass exists for the kernel that ran.
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -105,6 +106,21 @@ def spawn_ranks(n):
     return rc
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on STDOUT when a communicator is created; stdout carries the
+    one JSON line, so the banner is sent to stderr (file-descriptor level: it comes from C)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_ranks(a):
     """(rank, world, local device, dist or None): joins the process group the launcher described
     and proves that ``--gpus`` ranks are really there."""
@@ -121,15 +137,18 @@ def init_ranks(a):
         return rank, world, local, None
     import torch.distributed as dist
     backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
-    if backend == "nccl":
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dev = torch.device("cuda", local)
-    else:
-        dist.init_process_group(backend)
-        dev = torch.device("cpu")
-    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t)
+    with stdout_to_stderr():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dev = torch.device("cuda", local)
+        else:
+            dist.init_process_group(backend)
+            dev = torch.device("cpu")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
     if dist.get_world_size() != a.gpus or t.item() != a.gpus * (a.gpus + 1) / 2:
         raise SystemExit("bench.py: process group has %d ranks (all_reduce check %.1f), --gpus %d"
                          % (dist.get_world_size(), t.item(), a.gpus))
@@ -322,7 +341,9 @@ def main():
     c1 = run.engine.ctx.counters()
     dt = t1 - t0
     sims = c1["sims"] - c0["sims"]          # simulations completed (backed up) in the timed region
-    tot = torch.tensor([float(sims), dt], dtype=torch.float64, device=dev)
+    # the two reductions of the result travel on the process group's own device type
+    rdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    tot = torch.tensor([float(sims), dt], dtype=torch.float64, device=rdev)
     if world > 1:
         s = tot.clone()
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
