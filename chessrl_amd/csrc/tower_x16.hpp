@@ -1,0 +1,362 @@
+// tower_x16.hpp -- the fused residual trunk (design: tower_common.hpp; pipeline: tower_pipe.hpp /
+// tower_gen.hpp) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
+//
+// Why: the trunk is matrix-pipe bound on a POWER-limited clock.  With the same 64x64 wave tile,
+// the same LDS bytes per MAC and the same 64 accumulator registers, a 16x16x32 loop sustains
+// 1.14x the FLOP/s of the 32x32x16 loop on MI355X (tools/ubench/mfma_shapes.hip: 1780 vs 1554
+// TFLOP/s with every operand re-read from LDS; MI355X_MICROARCH.md, DVFS give-back item 7: equal
+// cycles per FLOP, higher held clock).  Results are NOT bit-identical to the 32x32x16 kernels:
+// the K = 32 contraction of one instruction sums in a different order (both accumulate fp32).
+//
+// What changes against tower_gen.hpp:
+//   * a wave tile of MT x NT 32x32 blocks becomes PT x CT = 2MT x 2NT blocks of 16 positions x 16
+//     channels; a sub-step is 32 input channels: PT + CT fragment reads feed PT*CT MFMAs;
+//   * fragment lanes: lane l = 16 q + r reads row r of its block, 16-byte quarter q of the 64-byte
+//     K block.  Activation rows are padded to (2 mod 16) 16-byte units (288 / 544 bytes): the 16
+//     lanes of a ds_read_b128 group -- 8 rows at quarter q, 8 at q+1 -- then cover all 64 banks;
+//   * weight tiles keep their global format ([F out][KT in] rows); the 32-channel tiles of the
+//     256-filter tower use the chunk swizzle (-(row >> 2)) & 3 in LDS;
+//   * the accumulator of block (pt, ct) holds, per lane, 4 consecutive channels 16 ct + 4 q + j of
+//     position 16 pt + r: the epilogue still writes 8-byte words into the LDS image in place;
+//   * the head convolutions reduce 4 CG partial sums per output (4 lane quarters x CG waves).
+#pragma once
+#include "tower_gen.hpp"
+
+namespace crl_tower {
+
+template <int F, int NB_>
+struct Geo16 {
+    static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
+    static constexpr int NB = NB_;                      // boards per workgroup
+    static constexpr int WPB = 8 / NB;                  // waves per board
+    static constexpr int NT = (F == 64 && NB == 2) ? 1 : 2;
+    static constexpr int CT = 2 * NT;                   // 16-channel blocks per wave
+    static constexpr int CG = F / (16 * CT);            // channel groups (waves splitting the channels)
+    static constexpr int PH = WPB / CG;                 // position halves (waves splitting a board)
+    static constexpr int PT = 4 / PH;                   // 16-position blocks per wave
+    static_assert(NB * CG * PH == 8 && (PH == 1 || PH == 2), "8 waves per workgroup");
+    static constexpr int KT = F == 256 ? 32 : 64;       // input channels per weight tile
+    static constexpr int SPT = KT / 32;                 // 32-channel sub-steps per tile
+    static constexpr int WROW = KT * 2;
+    static constexpr int WCH = WROW / 16;
+    static constexpr int TILE_BYTES = F * WROW;
+    static constexpr int GL = TILE_BYTES / 8192;
+    static constexpr int AROW = (F < 128 ? 128 : F) * 2 + 32;
+    static constexpr int ABOARD = 64 * AROW;
+    static constexpr int ZERO_OFF = NB * ABOARD;
+    static constexpr int ZERO_BYTES = 16 * AROW;
+    static constexpr int BIAS_OFF = ZERO_OFF + ZERO_BYTES;          // float [F], current layer
+    static constexpr int WRING_OFF = ((BIAS_OFF + F * 4 + 1023) / 1024) * 1024;
+    static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __device__ static int wswz(int row) { return WCH == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int N> __device__ __forceinline__ void wait_lgkm()
+{
+    static_assert(N >= 0 && N <= 8 && N != 7, "lgkmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+}
+
+//   planes  fp16 [n_boards][64][128], or 128 plane bitboards per board (BITS)
+//   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
+//   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
+//   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
+template <int F, int NB, int BITS = 0>
+__global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
+                                                       const unsigned char *__restrict__ wts,
+                                                       const float *__restrict__ bias,
+                                                       float *__restrict__ out, int n_blocks,
+                                                       const float *__restrict__ head_w,
+                                                       const float *__restrict__ head_b,
+                                                       float *__restrict__ head_out)
+{
+    typedef Geo16<F, NB> G;
+    constexpr int PT = G::PT, CT = G::CT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    lds_byte *lds = (lds_byte *)lds_raw;
+    const int lds_base = (int)(size_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int board = wave / G::WPB;
+    const int obase = (16 * CT) * ((wave / G::PH) % G::CG);      // first output channel of this wave
+    const int pbase = 32 * (wave % G::PH);              // first position of this wave
+    const int r = lane & 15, q = lane >> 4;
+    const int n_convs = 1 + 2 * n_blocks;
+    const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
+    const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
+    const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
+
+    stage_wtile_gen<G>(wts, lds, 0, tid);
+    stage_wtile_gen<G>(wts, lds, 1, tid);
+    stage_wtile_gen<G>(wts, lds, 2, tid);
+
+    {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
+        if constexpr (BITS) {
+            expand_bitplanes<G::NB, G::AROW, G::ABOARD>(planes, lds, wg_board0, tid);
+        } else {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
+#pragma unroll
+            for (int i = 0; i < G::NB * 2; i++) {
+                const int c16 = i * 512 + tid;
+                const int p = (c16 >> 4) & 63, c = c16 & 15, b = c16 >> 10;
+                u32x4 v = src[c16];
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(
+                    lds + b * G::ABOARD + p * G::AROW + (c << 4)) = v;
+            }
+        }
+        for (int i = tid; i < G::ZERO_BYTES / 16; i += 512)
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =
+                u32x4{0u, 0u, 0u, 0u};
+    }
+    wait_vmcnt<2 * G::GL>();                            // tile 0 landed (tiles 1,2 may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // position of the lane in block pt: p = pbase + 16 pt + r, i.e. file r & 7, rank (pbase >> 3) + 2 pt + (r >> 3)
+    const int px = r & 7, py0 = (pbase >> 3) + (r >> 3);
+    const int base0 = lds_base + board * G::ABOARD + (pbase + r) * G::AROW + q * 16;   // block 0's own row
+    const int zero_q = lds_base + G::ZERO_OFF + q * 16;
+    int waddr[CT][G::SPT];                              // weight fragment offset inside a tile
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const int o = obase + 16 * ct + r;
+#pragma unroll
+        for (int s = 0; s < G::SPT; s++) waddr[ct][s] = o * G::WROW + (((4 * s + q) ^ G::wswz(o)) << 4);
+    }
+
+    f32x4v res[PT][CT];                                 // fp32 residual stream
+#pragma unroll
+    for (int a = 0; a < PT; a++)
+#pragma unroll
+        for (int b = 0; b < CT; b++) res[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int HP = PT / 2;                          // position blocks per half sub-step
+
+    int t = 0;                                          // tile of the K-step being computed
+    for (int conv = 0; conv < n_convs; conv++) {
+        f32x4v acc[PT][CT];
+#pragma unroll
+        for (int a = 0; a < PT; a++)
+#pragma unroll
+            for (int b = 0; b < CT; b++) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        // this layer's bias: fetched now, parked in LDS just before the epilogue barrier
+        const float bias_reg = tid < F ? bias[conv * F + tid] : 0.f;
+
+        // Fragment registers: a sub-step (32 channels) runs as two halves of PT/2 position blocks
+        // against all CT channel blocks.  xa / xb: the activation fragments of the two halves;
+        // w[2]: this sub-step's weight fragments and the next one's.  Half 0 prefetches xb (HP
+        // reads); half 1 prefetches the next sub-step's xa and weights (HP + CT reads).
+        half8 xa[HP], xb[HP], w[2][CT];
+        int ab[2][PT];                                  // [current tap, next tap][pt]
+
+        // one (virtual) tap = NS sub-steps of 32 input channels; sub-step i reads channel block i of
+        // the tap's activation rows and sub-step i % SPT of weight tile t_tap0 + i / SPT
+        auto run_tap = [&](auto NSC, bool first_tap, bool last_tap) {
+            constexpr int NS = decltype(NSC)::value;
+            const int t_tap0 = t;
+            auto fetch_xa = [&](auto IC, bool next_tap) {
+                constexpr int i = decltype(IC)::value;
+#pragma unroll
+                for (int pt = 0; pt < HP; pt++) xa[pt] = lds_read16_asm<i * 64>(ab[next_tap ? 1 : 0][pt]);
+            };
+            auto fetch_xb = [&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+#pragma unroll
+                for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
+            };
+            auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
+                constexpr int i = decltype(IC)::value;
+                const int tile = next_tap ? t_tap0 + NS / G::SPT : t_tap0 + i / G::SPT;
+                const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * G::TILE_BYTES;
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) dst[ct] = lds_read16_asm<0>(wb + waddr[ct][i % G::SPT]);
+            };
+            if (first_tap) {
+                fetch_xa(std::integral_constant<int, 0>{}, false);
+                fetch_w(std::integral_constant<int, 0>{}, false, w[0]);
+            }
+            static_for<0, NS>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                constexpr int s = i % G::SPT;
+                constexpr int cur = i % 2, nxt = 1 - cur;
+                if constexpr (s == G::SPT - 1) {
+                    // publish tile t+1 before the half that prefetches its first fragments;
+                    // recycle tile t-1's slot
+                    if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 3 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 3, tid);
+                }
+                // ---- half 0: position blocks [0, HP)
+                fetch_xb(IC);
+                wait_lgkm<HP>();                         // xa and w[cur] have landed
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pt = 0; pt < HP; pt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++)
+                        acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xa[pt], acc[pt][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- half 1: position blocks [HP, PT); prefetch the next sub-step
+                constexpr bool wrap = i + 1 >= NS;
+                bool issued = false;
+                if (!wrap || !last_tap) {
+                    issued = true;
+                    if constexpr (wrap) {
+                        fetch_xa(std::integral_constant<int, 0>{}, true);
+                        fetch_w(std::integral_constant<int, 0>{}, true, w[nxt]);
+                    } else {
+                        fetch_xa(std::integral_constant<int, i + 1>{}, false);
+                        fetch_w(std::integral_constant<int, i + 1>{}, false, w[nxt]);
+                    }
+                }
+                if (!issued) wait_lgkm<0>();
+                else wait_lgkm<HP + CT>();               // xb has landed
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pt = 0; pt < HP; pt++)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct++)
+                        acc[HP + pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xb[pt], acc[HP + pt][ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == G::SPT - 1) t++;
+            });
+        };
+
+        // A spatial tap with more than 128 input channels runs as Cin/128 "virtual taps" of 128
+        // channels each (same neighbour rows, channel offset 256 bytes further): every virtual tap
+        // is NS = 4 sub-steps, one unrolled body for the stem and the 128- and 256-filter layers.
+        const int hshift = (conv != 0 && F == 256) ? 1 : 0;
+        const int nv = 9 << hshift;
+        // Activation row address of block pt for virtual tap v: the lane's own row shifted by
+        // (8 dy + dx) rows when that neighbour is on the board, else the zero row whose index has
+        // the same residue mod 16 (same banks).  The zero-row address and the file test do not
+        // depend on pt: per block only the rank test and one select remain.
+        auto vtap_rows = [&](int v, int (&dst)[PT]) {
+            const int tap = v >> hshift;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int shift = 8 * dy + dx;
+            const int choff = (v & ((1 << hshift) - 1)) * 256;
+            const int zrow = zero_q + ((r + shift) & 15) * G::AROW + choff;
+            const int inb = base0 + shift * G::AROW + choff;
+            const bool xok = (unsigned)(px + dx) < 8u;
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) {
+                const bool ok = xok && (unsigned)(py0 + 2 * pt + dy) < 8u;
+                dst[pt] = ok ? inb + pt * 16 * G::AROW : zrow;
+            }
+        };
+        vtap_rows(0, ab[1]);
+        for (int v = 0; v < nv; v++) {
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) ab[0][pt] = ab[1][pt];
+            vtap_rows(v + 1 < nv ? v + 1 : 0, ab[1]);
+            if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, v == 0, v == nv - 1);
+            else run_tap(std::integral_constant<int, 4>{}, v == 0, v == nv - 1);
+        }
+
+        // ---- epilogue ------------------------------------------------------------------------------
+        if (tid < F)
+            *reinterpret_cast<__attribute__((address_space(3))) float *>(lds + G::BIAS_OFF + tid * 4) = bias_reg;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // all reads of the activation buffer done
+        __builtin_amdgcn_sched_barrier(0);
+        const bool is_stem = conv == 0;
+        const bool is_conv2 = !is_stem && ((conv & 1) == 0);
+        const bool keep_res = !is_stem && !is_conv2;
+        const float relu_floor = is_stem ? -__builtin_inff() : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int o0 = obase + 16 * ct + 4 * q;     // 4 consecutive channels
+            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
+                lds + G::BIAS_OFF + o0 * 4);
+#pragma unroll
+            for (int pt = 0; pt < PT; pt++) {
+                const int p = pbase + 16 * pt + r;
+                half4 o16;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float skip = is_conv2 ? res[pt][ct][j] : 0.f;
+                    float v = (acc[pt][ct][j] + bv[j]) + skip;
+                    v = fmaxf(v, relu_floor);
+                    res[pt][ct][j] = keep_res ? res[pt][ct][j] : v;
+                    o16[j] = (_Float16)v;
+                }
+                *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
+                    lds + board * G::ABOARD + p * G::AROW + o0 * 2) = o16;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (out) {
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            const int p = pbase + 16 * pt + r;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                const int o0 = obase + 16 * ct + 4 * q;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = res[pt][ct][j];
+                *reinterpret_cast<f32x4 *>(out + ((wg_board0 + board) * 64 + p) * F + o0) = v;
+            }
+        }
+    }
+
+    if (head_out) {
+        // a position's F channels live in CG waves x 4 lane quarters: 4*CG partial sums per output,
+        // added in a fixed order (no float atomics: results are reproducible)
+        constexpr int NC = 4 * G::CG;
+        float part[PT][3];
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) part[pt][k] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int o0 = obase + 16 * ct + 4 * q;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(head_w + k * F + o0);
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) part[pt][k] += res[pt][ct][j] * wv[j];
+            }
+        }
+        __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                scratch[(((board * 64 + pbase + 16 * pt + r) * 3) + k) * NC + (obase / (16 * CT)) * 4 + q] = part[pt][k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int i = tid; i < G::NB * 64 * 3; i += 512) {
+            const int k = i % 3, bp = i / 3;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v += scratch[i * NC + c];      // fixed order
+            v += head_b[k];
+            const size_t gb = wg_board0 + (bp >> 6);
+            const int pos = bp & 63;
+            head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
+        }
+    }
+}
+
+}  // namespace crl_tower

@@ -1,0 +1,147 @@
+// Scratch (GPU): time correct-result variants of the fused trunk kernels against production and
+// check that their outputs are bit-identical.  hipcc --offload-arch=gfx950 -O3 -std=c++17
+// -ffp-contract=off -I chessrl_amd/csrc tools/ubench/trunk_variants.hip -o tools/ubench/trunk_variants
+//   ./trunk_variants [boards=4096] [reps=20]
+#include "tower_pipe.hpp"
+#include "tower_gen.hpp"
+#include "tower_x16.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace crl_tower;
+typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
+                       const float *, const float *, float *);
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Bufs { unsigned char *planes, *wts; float *bias, *head_w, *head_b, *head_out; };
+
+static uint32_t rng_state = 12345;
+static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+
+static double run(const char *name, kern_t k, int lds, int boards_per_wg, int F, int blocks, int boards, int reps,
+                  const Bufs &b, std::vector<float> &out, const std::vector<float> *ref)
+{
+    if (const char *only = getenv("ONLY")) {              // profiling: run just the kernels whose label matches
+        if (!strstr(name, only)) return 0;
+        CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int i = 0; i < 3; i++)
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+        CK(hipDeviceSynchronize());
+        printf("ran %s x3\n", name);
+        return 0;
+    }
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipMemset(b.head_out, 0, (size_t)boards * 192 * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double best = 1e9;
+    for (int round = 0; round < 3; round++) {
+        for (int i = 0; i < 2; i++)
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; i++)
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / reps < best) best = ms / reps;
+    }
+    CK(hipGetLastError());
+    out.resize((size_t)boards * 192);
+    CK(hipMemcpy(out.data(), b.head_out, out.size() * 4, hipMemcpyDeviceToHost));
+    const double flops = 2.0 * (73152.0 * F + 1152.0 * F * F * blocks + 192.0 * F) * boards;
+    bool same = !ref || memcmp(ref->data(), out.data(), out.size() * 4) == 0;
+    double sum = 0, maxd = 0, maxv = 0;
+    for (size_t i = 0; i < out.size(); i++) {
+        sum += out[i];
+        if (ref) { double d = fabs((double)out[i] - (*ref)[i]); if (d > maxd) maxd = d; if (fabs((*ref)[i]) > maxv) maxv = fabs((*ref)[i]); }
+    }
+    char cmp[96];
+    if (!ref) snprintf(cmp, sizeof cmp, "reference");
+    else if (same) snprintf(cmp, sizeof cmp, "bit-identical");
+    else snprintf(cmp, sizeof cmp, "max|d| %.3g of max %.3g", maxd, maxv);
+    printf("%-34s %8.4f ms  %7.1f TFLOP/s  frac %.3f  %s (checksum %.6e)\n", name, best, flops / best / 1e9,
+           flops / best / 1e9 / 2500.0, cmp, sum);
+    fflush(stdout);
+    return best;
+}
+
+static Bufs make(int F, int blocks, int boards)
+{
+    Bufs b;
+    const int n_convs = 1 + 2 * blocks;
+    const size_t wbytes = ((size_t)9 * 128 * F + (size_t)2 * blocks * 9 * F * F) * 2;
+    std::vector<uint64_t> planes((size_t)boards * 128);
+    for (auto &p : planes) { uint64_t v = 0; for (int i = 0; i < 64; i++) if (rnd() % 8 == 0) v |= 1ull << i; p = v; }
+    std::vector<_Float16> w(wbytes / 2);
+    const float scale = 1.5f / sqrtf(9.0f * F);
+    for (auto &x : w) x = (_Float16)(((int)(rnd() % 2001) - 1000) * 1e-3f * scale);
+    std::vector<float> bias((size_t)n_convs * F), hw(3 * F), hb(3);
+    for (auto &x : bias) x = ((int)(rnd() % 201) - 100) * 1e-3f;
+    for (auto &x : hw) x = ((int)(rnd() % 201) - 100) * 1e-3f;
+    for (auto &x : hb) x = 0.1f;
+    CK(hipMalloc(&b.planes, planes.size() * 8)); CK(hipMemcpy(b.planes, planes.data(), planes.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.wts, wbytes)); CK(hipMemcpy(b.wts, w.data(), wbytes, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.bias, bias.size() * 4)); CK(hipMemcpy(b.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.head_w, hw.size() * 4)); CK(hipMemcpy(b.head_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.head_b, 12)); CK(hipMemcpy(b.head_b, hb.data(), 12, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b.head_out, (size_t)boards * 192 * 4));
+    return b;
+}
+
+int main(int argc, char **argv)
+{
+    const int boards = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 20;
+    std::vector<float> ref, out;
+    {
+        Bufs b = make(128, 10, boards);
+        printf("== 10 x 128, %d boards\n", boards);
+        run("k_trunk128_pipe<0,1> production", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, ref, nullptr);
+        run("  <64,1> weights via registers", k_trunk128_pipe<64, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("  <128,1> waves 4-7 half a step late", k_trunk128_pipe<128, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("  <192,1> both", k_trunk128_pipe<192, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk128_pipe<0,1> again", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,4,1> 16x16x32", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,2,1> 512 boards", k_trunk_x16<128, 2, 1>, Geo16<128, 2>::LDS_BYTES, 2, 128, 10, 512, reps, b, out, nullptr);
+    }
+    if (argc > 3 && atoi(argv[3]) == 0) return 0;
+    {
+        Bufs b = make(256, 20, boards);
+        printf("== 20 x 256, %d boards\n", boards);
+        typedef Geo<256, 2> G;
+        run("k_trunk_gen<256,2,1> production", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, ref, nullptr);
+        run("  VAR 2 waves 4-7 half a tile late", k_trunk_gen<256, 2, 1, 2>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
+        run("  VAR 4 barrier per two tiles, ring 5", k_trunk_gen<256, 2, 1, 4>, G::lds_bytes(5), 2, 256, 20, boards, 5, b, out, &ref);
+        run("  VAR 6 both", k_trunk_gen<256, 2, 1, 6>, G::lds_bytes(5), 2, 256, 20, boards, 5, b, out, &ref);
+        run("  VAR 1 weights via registers", k_trunk_gen<256, 2, 1, 1>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
+        run("  VAR 3 registers + late half", k_trunk_gen<256, 2, 1, 3>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_x16<256,2,1> 16x16x32", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+    }
+    {
+        Bufs b = make(64, 6, boards);
+        printf("== 6 x 64, %d boards (4-board workgroups), then 512 boards (2-board workgroups)\n", boards);
+        typedef Geo<64, 4> G4; typedef Geo<64, 2> G2;
+        run("k_trunk_gen<64,4,1> production", k_trunk_gen<64, 4, 1, 0>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, ref, nullptr);
+        run("  VAR 2 late half", k_trunk_gen<64, 4, 1, 2>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
+        run("  VAR 1 registers", k_trunk_gen<64, 4, 1, 1>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
+        run("  VAR 3 both", k_trunk_gen<64, 4, 1, 3>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
+        run("k_trunk_x16<64,4,1> 16x16x32", k_trunk_x16<64, 4, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
+        run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1, 0>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, ref, nullptr);
+        run("  VAR 2 late half", k_trunk_gen<64, 2, 1, 2>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
+        run("  VAR 1 registers", k_trunk_gen<64, 2, 1, 1>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
+        run("  VAR 3 both", k_trunk_gen<64, 2, 1, 3>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
+        run("k_trunk_x16<64,2,1> 16x16x32 512", k_trunk_x16<64, 2, 1>, Geo16<64, 2>::LDS_BYTES, 2, 64, 6, 512, reps, b, out, &ref);
+    }
+    {
+        Bufs b = make(128, 10, boards);
+        printf("== 10 x 128 through the template, %d boards\n", boards);
+        typedef Geo<128, 4> G;
+        run("k_trunk_gen<128,4,1>", k_trunk_gen<128, 4, 1, 0>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, ref, nullptr);
+        run("  VAR 2 late half", k_trunk_gen<128, 4, 1, 2>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, out, &ref);
+        run("  VAR 1 registers", k_trunk_gen<128, 4, 1, 1>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, out, &ref);
+    }
+    return 0;
+}
