@@ -213,11 +213,9 @@ def pmc_traffic(kernel, shape):
 
 def trunk_kernel_name(F, G, bits):
     """The dispatch rule of crl_trunk_forward (csrc/api.hip), as rocprofv3 prints the kernel."""
-    if G <= 128 * (2 if F == 256 else 4):
-        return "k_trunk_gen<%d, %d, %d>" % (F, 1 if F == 256 else 2, bits)
-    if F == 128:
-        return "k_trunk128_pipe<0, %d>" % bits
-    return "k_trunk_gen<%d, %d, %d>" % (F, 2 if F == 256 else 4, bits)
+    small = G <= 128 * (2 if F == 256 else 4)
+    nb = {64: (2 if small else 4), 128: (2 if small else 4), 256: (1 if small else 2)}[F]
+    return "k_trunk_x16<%d, %d, %d>" % (F, nb, bits)
 
 
 def cpu_baseline(seconds):

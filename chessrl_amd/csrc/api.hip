@@ -7,6 +7,7 @@
 #endif
 #include "tower_pipe.hpp"
 #include "tower_gen.hpp"
+#include "tower_x16.hpp"
 #include "train_ops.hpp"
 
 #include <atomic>
@@ -571,28 +572,47 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
-    kern_t kern = bits ? crl_tower::k_trunk128_pipe<0, 1> : crl_tower::k_trunk128_pipe<0, 0>;   // production, 128 filters
-    int lds_bytes = crl_tower::P2_LDS_BYTES;
-    int boards_per_wg = crl_tower::BOARDS_PER_WG;
+    kern_t kern = nullptr;
+    int lds_bytes = 0, boards_per_wg = 0;
     // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
     // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
     const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
+    // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count
+#define CRL_X16(F_, NB_)                                                                        \
+    do {                                                                                         \
+        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1> : crl_tower::k_trunk_x16<F_, NB_, 0>;   \
+        lds_bytes = crl_tower::Geo16<F_, NB_>::LDS_BYTES;                                        \
+        boards_per_wg = NB_;                                                                     \
+    } while (0)
+    if (filters == 256) {
+        if (small) CRL_X16(256, 1); else CRL_X16(256, 2);
+    } else if (filters == 64) {
+        if (small) CRL_X16(64, 2); else CRL_X16(64, 4);
+    } else {
+        if (small) CRL_X16(128, 2); else CRL_X16(128, 4);
+    }
+#undef CRL_X16
+#ifdef CRL_TUNING
+    // tuning library: the 32x32x16 kernels (tower_pipe.hpp / tower_gen.hpp / tower.hpp) by variant
 #define CRL_GEN(F_, NB_)                                                                        \
     do {                                                                                         \
         kern = bits ? crl_tower::k_trunk_gen<F_, NB_, 1> : crl_tower::k_trunk_gen<F_, NB_, 0>;   \
         lds_bytes = crl_tower::Geo<F_, NB_>::LDS_BYTES;                                          \
         boards_per_wg = NB_;                                                                     \
     } while (0)
-    if (filters == 256) {
-        if (small) CRL_GEN(256, 1); else CRL_GEN(256, 2);
-    } else if (filters == 64) {
-        if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4);
-    } else if (small) {
-        CRL_GEN(128, 2);
-    }
-#ifdef CRL_TUNING
-    else if (!bits && tuning_variant() != 0) {
+    if (tuning_variant() == 400) {                       // 32x32x16 production set of round 1
+        if (filters == 256) { if (small) CRL_GEN(256, 1); else CRL_GEN(256, 2); }
+        else if (filters == 64) { if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4); }
+        else if (small) CRL_GEN(128, 2);
+        else {
+            kern = bits ? crl_tower::k_trunk128_pipe<0, 1> : crl_tower::k_trunk128_pipe<0, 0>;
+            lds_bytes = crl_tower::P2_LDS_BYTES;
+            boards_per_wg = crl_tower::BOARDS_PER_WG;
+        }
+    } else if (filters == 128 && !small && !bits && tuning_variant() != 0) {
         const int first = crl_tower::LDS_BYTES;        // LDS size of the first-build kernels
+        lds_bytes = crl_tower::P2_LDS_BYTES;
+        boards_per_wg = crl_tower::BOARDS_PER_WG;
         switch (tuning_variant()) {
         case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = first; break;    // unpipelined baseline
         case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = first; break;     // + s_setprio
@@ -605,6 +625,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         case 104: kern = crl_tower::k_trunk128<104>; lds_bytes = first; break;
         case 105: kern = crl_tower::k_trunk128<105>; lds_bytes = first; break;
         case 106: kern = crl_tower::k_trunk128<106>; lds_bytes = first; break;
+        case 200: kern = crl_tower::k_trunk128_pipe<0>; break;                 // round-1 production
         case 201: kern = crl_tower::k_trunk128_pipe<1>; break;                 // 201..203 timing only
         case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
         case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
@@ -612,12 +633,14 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         case 216: kern = crl_tower::k_trunk128_pipe<16>; break;                // x reads for dx = 0 only
         case 232: kern = crl_tower::k_trunk128_pipe<32>; break;                // no vmcnt wait for the DMA
         case 234: kern = crl_tower::k_trunk128_pipe<34>; break;                // ... and no barrier
+        case 264: kern = crl_tower::k_trunk128_pipe<64>; break;                // weights via registers
+        case 328: kern = crl_tower::k_trunk128_pipe<128>; break;               // waves 4-7 half a step late
         case 300: CRL_GEN(128, 4); break;                                      // the template at F = 128
-        default: break;
+        default: kern = crl_tower::k_trunk_x16<128, 4, 0>; lds_bytes = crl_tower::Geo16<128, 4>::LDS_BYTES; break;
         }
     }
-#endif
 #undef CRL_GEN
+#endif
     hipError_t ea = allow_big_lds((const void *)kern, lds_bytes);
     if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
     hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),

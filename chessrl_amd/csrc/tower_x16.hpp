@@ -49,8 +49,52 @@ struct Geo16 {
     static constexpr int WRING_OFF = ((BIAS_OFF + F * 4 + 1023) / 1024) * 1024;
     static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    __device__ static int wswz(int row) { return WCH == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); }
+    // LDS image of a weight tile: one plane per 32-channel sub-step, [SPT][F rows][64 bytes];
+    // rows of 16 banks, chunk swizzle (-(row >> 2)) & 3: the 16 lanes of a ds_read_b128 group (8
+    // rows at quarter q, 8 at q+1) cover all 64 banks, and the sub-step is an immediate offset.
+    static constexpr int WPLANE = F * 64;
+    __device__ static int wswz(int row) { return (0 - (row >> 2)) & 3; }
 };
+
+// stage weight tile t (global format [F out][KT in]) into ring slot t & 3 as the plane image above.
+// ALT = 0: every wave moves GL pieces of 1 KiB.  ALT = 1: the tile is moved by ONE half of the
+// workgroup -- waves 0-3 move even tiles, waves 4-7 odd tiles, 2 GL pieces each -- so that of the
+// two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
+// goes straight back to its MFMAs.
+template <class G, int ALT>
+__device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, int t, int tid, int wave_u)
+{
+    const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
+    const int slot0 = G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
+    if constexpr (ALT) {
+        if ((wave_u >> 2) != (t & 1)) return;
+        const int dst0 = slot0 + (wave_u & 3) * 1024;   // uniform
+#pragma unroll
+        for (int j = 0; j < 2 * G::GL; j++) {
+            const int idx = j * 256 + (tid & 255);      // 16-byte slot of the LDS image
+            const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
+            const int row = rem >> 2, phys = rem & 3;
+            const int chunk = phys ^ G::wswz(row);
+            const unsigned off = (unsigned)(row * G::WROW + ksub * 64 + chunk * 16);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + off),
+                (__attribute__((address_space(3))) void *)(lds + dst0 + j * 4096), 16, 0, 0);
+        }
+    } else {
+        const int dst0 = slot0 + wave_u * 1024;         // uniform
+#pragma unroll
+        for (int j = 0; j < G::GL; j++) {
+            const int idx = j * 512 + tid;              // 16-byte slot of the LDS image
+            const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
+            const int row = rem >> 2, phys = rem & 3;
+            const int chunk = phys ^ G::wswz(row);
+            const unsigned off = (unsigned)(row * G::WROW + ksub * 64 + chunk * 16);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + off),
+                (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
+        }
+    }
+}
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -71,7 +115,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 //   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
-template <int F, int NB, int BITS = 0>
+template <int F, int NB, int BITS = 0, int ALT = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -90,14 +134,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int obase = (16 * CT) * ((wave / G::PH) % G::CG);      // first output channel of this wave
     const int pbase = 32 * (wave % G::PH);              // first position of this wave
     const int r = lane & 15, q = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int n_convs = 1 + 2 * n_blocks;
     const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
-    stage_wtile_gen<G>(wts, lds, 0, tid);
-    stage_wtile_gen<G>(wts, lds, 1, tid);
-    stage_wtile_gen<G>(wts, lds, 2, tid);
+    stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u);
+    stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u);
+    stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u);
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
         if constexpr (BITS) {
@@ -117,7 +162,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =
                 u32x4{0u, 0u, 0u, 0u};
     }
-    wait_vmcnt<2 * G::GL>();                            // tile 0 landed (tiles 1,2 may be in flight)
+    // tile 0 landed (tiles 1,2 may be in flight).  ALT: waves 0-3 moved tiles 0 and 2, waves 4-7 tile 1
+    if constexpr (ALT) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
+    else wait_vmcnt<2 * G::GL>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -126,13 +173,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int px = r & 7, py0 = (pbase >> 3) + (r >> 3);
     const int base0 = lds_base + board * G::ABOARD + (pbase + r) * G::AROW + q * 16;   // block 0's own row
     const int zero_q = lds_base + G::ZERO_OFF + q * 16;
-    int waddr[CT][G::SPT];                              // weight fragment offset inside a tile
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-        const int o = obase + 16 * ct + r;
-#pragma unroll
-        for (int s = 0; s < G::SPT; s++) waddr[ct][s] = o * G::WROW + (((4 * s + q) ^ G::wswz(o)) << 4);
-    }
+    const int act_row0 = board * G::ABOARD + (pbase + r) * G::AROW;    // the lane's row in block 0
+    // Weight fragment address: row o = obase + 16 ct + r of a tile plane, quarter q.  The swizzle
+    // (-(o >> 2)) & 3 does not depend on ct (16 ct >> 2 is a multiple of 4), so ONE per-lane address
+    // serves every channel block, sub-step and tile of a tap through the immediate offset
+    // ct * 1024 + sub-step plane + tile slot; only the tap's first ring slot is added per tap.
+    const int w0 = lds_base + G::WRING_OFF + (obase + r) * 64 + ((q ^ G::wswz(obase + r)) << 4);
+    static_assert((16 * 64) == 1024 && G::TILE_BYTES * 2 + G::WPLANE + 3 * 1024 < 65536, "ds_read immediate");
 
     f32x4v res[PT][CT];                                 // fp32 residual stream
 #pragma unroll
@@ -174,12 +221,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
             };
+            // a tap's tiles sit in consecutive ring slots (a tap is 1, 2 or 4 tiles and starts on a
+            // multiple of that): slot and sub-step are immediates on top of the tap's first slot
+            static_assert((NS / G::SPT == 1 || NS / G::SPT == 2 || NS / G::SPT == 4) && PIPE_RING == 4, "ring");
+            const int wv_cur = w0 + (t_tap0 & (PIPE_RING - 1)) * G::TILE_BYTES;
+            const int wv_nxt = w0 + ((t_tap0 + NS / G::SPT) & (PIPE_RING - 1)) * G::TILE_BYTES;
             auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
                 constexpr int i = decltype(IC)::value;
-                const int tile = next_tap ? t_tap0 + NS / G::SPT : t_tap0 + i / G::SPT;
-                const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * G::TILE_BYTES;
-#pragma unroll
-                for (int ct = 0; ct < CT; ct++) dst[ct] = lds_read16_asm<0>(wb + waddr[ct][i % G::SPT]);
+                static_for<0, CT>([&](auto CC) {
+                    constexpr int ct = decltype(CC)::value;
+                    constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (i / G::SPT) * G::TILE_BYTES;
+                    dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv_cur);
+                });
             };
             if (first_tap) {
                 fetch_xa(std::integral_constant<int, 0>{}, false);
@@ -192,11 +245,17 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 if constexpr (s == G::SPT - 1) {
                     // publish tile t+1 before the half that prefetches its first fragments;
                     // recycle tile t-1's slot
-                    if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
-                    else wait_vmcnt<0>();
+                    if constexpr (ALT) {
+                        // tile t+1 was moved by the half with (t+1) & 1, three syncs ago, and is
+                        // the only transfer that half has in flight
+                        if ((wave_u >> 2) == ((t + 1) & 1)) wait_vmcnt<0>();
+                    } else {
+                        if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
+                        else wait_vmcnt<0>();
+                    }
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t + 3 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 3, tid);
+                    if (t + 3 < n_tiles) stage_wtile_x16<G, ALT>(wts, lds, t + 3, tid, wave_u);
                 }
                 // ---- half 0: position blocks [0, HP)
                 fetch_xb(IC);
@@ -272,10 +331,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // all reads of the activation buffer done
         __builtin_amdgcn_sched_barrier(0);
-        const bool is_stem = conv == 0;
-        const bool is_conv2 = !is_stem && ((conv & 1) == 0);
-        const bool keep_res = !is_stem && !is_conv2;
-        const float relu_floor = is_stem ? -__builtin_inff() : 0.f;
+        // three wave-uniform shapes (branches, not selects: every VALU instruction competes with the
+        // partner wave's MFMAs for issue slots): stem = bias only (no BN, no activation,
+        // model.py:33-34); conv1 = ReLU, skip stream untouched; conv2 = + skip, ReLU, new skip
+        const int kind = conv == 0 ? 0 : ((conv & 1) ? 1 : 2);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             const int o0 = obase + 16 * ct + 4 * q;     // 4 consecutive channels
@@ -283,18 +342,27 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 lds + G::BIAS_OFF + o0 * 4);
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) {
-                const int p = pbase + 16 * pt + r;
                 half4 o16;
+                if (kind == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float skip = is_conv2 ? res[pt][ct][j] : 0.f;
-                    float v = (acc[pt][ct][j] + bv[j]) + skip;
-                    v = fmaxf(v, relu_floor);
-                    res[pt][ct][j] = keep_res ? res[pt][ct][j] : v;
-                    o16[j] = (_Float16)v;
+                    for (int j = 0; j < 4; j++) {
+                        const float v = acc[pt][ct][j] + bv[j];
+                        res[pt][ct][j] = v;
+                        o16[j] = (_Float16)v;
+                    }
+                } else if (kind == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)fmaxf(acc[pt][ct][j] + bv[j], 0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float v = fmaxf((acc[pt][ct][j] + bv[j]) + res[pt][ct][j], 0.f);
+                        res[pt][ct][j] = v;
+                        o16[j] = (_Float16)v;
+                    }
                 }
                 *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
-                    lds + board * G::ABOARD + p * G::AROW + o0 * 2) = o16;
+                    lds + act_row0 + pt * 16 * G::AROW + o0 * 2) = o16;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

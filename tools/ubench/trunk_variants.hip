@@ -104,6 +104,8 @@ int main(int argc, char **argv)
         run("  <192,1> both", k_trunk128_pipe<192, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk128_pipe<0,1> again", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> 16x16x32", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,4,1,1> alt issuer", k_trunk_x16<128, 4, 1, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,4,1> again", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,2,1> 512 boards", k_trunk_x16<128, 2, 1>, Geo16<128, 2>::LDS_BYTES, 2, 128, 10, 512, reps, b, out, nullptr);
     }
     if (argc > 3 && atoi(argv[3]) == 0) return 0;
@@ -119,6 +121,7 @@ int main(int argc, char **argv)
         run("  VAR 3 registers + late half", k_trunk_gen<256, 2, 1, 3>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1> 16x16x32", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_x16<256,2,1,1> alt issuer", k_trunk_x16<256, 2, 1, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
     }
     {
         Bufs b = make(64, 6, boards);
@@ -129,6 +132,7 @@ int main(int argc, char **argv)
         run("  VAR 1 registers", k_trunk_gen<64, 4, 1, 1>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
         run("  VAR 3 both", k_trunk_gen<64, 4, 1, 3>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
         run("k_trunk_x16<64,4,1> 16x16x32", k_trunk_x16<64, 4, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
+        run("k_trunk_x16<64,4,1,1> alt issuer", k_trunk_x16<64, 4, 1, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
         run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1, 0>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, ref, nullptr);
         run("  VAR 2 late half", k_trunk_gen<64, 2, 1, 2>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
         run("  VAR 1 registers", k_trunk_gen<64, 2, 1, 1>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
