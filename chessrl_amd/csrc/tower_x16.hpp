@@ -45,8 +45,8 @@ struct Geo16 {
     static constexpr int ABOARD = 64 * AROW;
     static constexpr int ZERO_OFF = NB * ABOARD;
     static constexpr int ZERO_BYTES = 16 * AROW;
-    static constexpr int BIAS_OFF = ZERO_OFF + ZERO_BYTES;          // float [F], current layer
-    static constexpr int WRING_OFF = ((BIAS_OFF + F * 4 + 1023) / 1024) * 1024;
+    static constexpr int BIAS_OFF = ZERO_OFF + ZERO_BYTES;          // float [2][F]: this layer's and the next one's
+    static constexpr int WRING_OFF = ((BIAS_OFF + 2 * F * 4 + 1023) / 1024) * 1024;
     static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     // LDS image of a weight tile: one plane per 32-channel sub-step, [SPT][F rows][64 bytes];
@@ -57,6 +57,8 @@ struct Geo16 {
 };
 
 // stage weight tile t (global format [F out][KT in]) into ring slot t & 3 as the plane image above.
+// (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5: timing-only builds without the weight staging, without
+// the per-tile barrier, without both -- harness diagnostics, WRONG results, never dispatched.)
 // ALT = 0: every wave moves GL pieces of 1 KiB.  ALT = 1: the tile is moved by ONE half of the
 // workgroup -- waves 0-3 move even tiles, waves 4-7 odd tiles, 2 GL pieces each -- so that of the
 // two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
@@ -66,7 +68,7 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
 {
     const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
     const int slot0 = G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
-    if constexpr (ALT) {
+    if constexpr (ALT == 1) {
         if ((wave_u >> 2) != (t & 1)) return;
         const int dst0 = slot0 + (wave_u & 3) * 1024;   // uniform
 #pragma unroll
@@ -94,6 +96,19 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
                 (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
         }
     }
+}
+
+// bias row of layer `conv` (F floats) -> LDS row conv & 1, by LDS-DMA: F/64 waves move 256 bytes each.
+// Being a DMA like the weight tiles it is covered by the same counted vmcnt waits and barriers; no
+// register, no ds_write and no compiler-inserted vmcnt(0) (which would drain the weight stream).
+template <class G, int F>
+__device__ inline void stage_bias_x16(const float *bias, lds_byte *lds, int conv, int lane, int wave_u)
+{
+    if (wave_u >= F / 64) return;
+    const float *src = bias + (size_t)conv * F + wave_u * 64;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(src + lane),
+        (__attribute__((address_space(3))) void *)(lds + G::BIAS_OFF + (conv & 1) * F * 4 + wave_u * 256), 4, 0, 0);
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
+    stage_bias_x16<G, F>(bias, lds, 0, lane, wave_u);   // oldest transfer: landed when tile 0 has
     stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u);
     stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u);
     stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u);
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 u32x4{0u, 0u, 0u, 0u};
     }
     // tile 0 landed (tiles 1,2 may be in flight).  ALT: waves 0-3 moved tiles 0 and 2, waves 4-7 tile 1
-    if constexpr (ALT) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
+    if constexpr (ALT == 1) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
     else wait_vmcnt<2 * G::GL>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -189,15 +205,22 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 
     constexpr int HP = PT / 2;                          // position blocks per half sub-step
 
+    constexpr bool STAMP = ALT == 2;                    // harness diagnostic: in-kernel cycle stamps
+    unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0;
+    if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); t_mark = t_begin; }
     int t = 0;                                          // tile of the K-step being computed
     for (int conv = 0; conv < n_convs; conv++) {
+        // the accumulators start from this layer's bias (LDS row conv & 1, staged one layer ahead):
+        // the first MFMA of every chain takes it as its C operand, the epilogue adds nothing
         f32x4v acc[PT][CT];
 #pragma unroll
-        for (int a = 0; a < PT; a++)
+        for (int ct = 0; ct < CT; ct++) {
+            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
+                lds + G::BIAS_OFF + (conv & 1) * F * 4 + (obase + 16 * ct + 4 * q) * 4);
 #pragma unroll
-            for (int b = 0; b < CT; b++) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        // this layer's bias: fetched now, parked in LDS just before the epilogue barrier
-        const float bias_reg = tid < F ? bias[conv * F + tid] : 0.f;
+            for (int pt = 0; pt < PT; pt++) acc[pt][ct] = f32x4v{bv[0], bv[1], bv[2], bv[3]};
+        }
+        bool bias_staged = false;                       // next layer's bias goes out with the first tile sync
 
         // Fragment registers: a sub-step (32 channels) runs as two halves of PT/2 position blocks
         // against all CT channel blocks.  xa / xb: the activation fragments of the two halves;
@@ -245,17 +268,22 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 if constexpr (s == G::SPT - 1) {
                     // publish tile t+1 before the half that prefetches its first fragments;
                     // recycle tile t-1's slot
-                    if constexpr (ALT) {
+                    if constexpr (ALT == 1) {
                         // tile t+1 was moved by the half with (t+1) & 1, three syncs ago, and is
                         // the only transfer that half has in flight
                         if ((wave_u >> 2) == ((t + 1) & 1)) wait_vmcnt<0>();
-                    } else {
+                    } else if constexpr (ALT < 3) {
                         if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
                         else wait_vmcnt<0>();
                     }
-                    __builtin_amdgcn_s_barrier();
+                    if constexpr (ALT != 4 && ALT != 5) __builtin_amdgcn_s_barrier();   // 4, 5: timing only
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t + 3 < n_tiles) stage_wtile_x16<G, ALT>(wts, lds, t + 3, tid, wave_u);
+                    if (!bias_staged) {
+                        bias_staged = true;
+                        if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
+                    }
+                    if constexpr (ALT != 3 && ALT != 5)                                  // 3, 5: timing only
+                        if (t + 3 < n_tiles) stage_wtile_x16<G, ALT>(wts, lds, t + 3, tid, wave_u);
                 }
                 // ---- half 0: position blocks [0, HP)
                 fetch_xb(IC);
@@ -326,37 +354,33 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         }
 
         // ---- epilogue ------------------------------------------------------------------------------
-        if (tid < F)
-            *reinterpret_cast<__attribute__((address_space(3))) float *>(lds + G::BIAS_OFF + tid * 4) = bias_reg;
+        if constexpr (STAMP) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_loop += now - t_mark; t_mark = now; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // all reads of the activation buffer done
         __builtin_amdgcn_sched_barrier(0);
         // three wave-uniform shapes (branches, not selects: every VALU instruction competes with the
-        // partner wave's MFMAs for issue slots): stem = bias only (no BN, no activation,
+        // partner wave's MFMAs for issue slots): stem = linear (no BN, no activation,
         // model.py:33-34); conv1 = ReLU, skip stream untouched; conv2 = + skip, ReLU, new skip
         const int kind = conv == 0 ? 0 : ((conv & 1) ? 1 : 2);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             const int o0 = obase + 16 * ct + 4 * q;     // 4 consecutive channels
-            const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
-                lds + G::BIAS_OFF + o0 * 4);
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) {
                 half4 o16;
                 if (kind == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float v = acc[pt][ct][j] + bv[j];
-                        res[pt][ct][j] = v;
-                        o16[j] = (_Float16)v;
+                        res[pt][ct][j] = acc[pt][ct][j];
+                        o16[j] = (_Float16)acc[pt][ct][j];
                     }
                 } else if (kind == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)fmaxf(acc[pt][ct][j] + bv[j], 0.f);
+                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)fmaxf(acc[pt][ct][j], 0.f);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float v = fmaxf((acc[pt][ct][j] + bv[j]) + res[pt][ct][j], 0.f);
+                        const float v = fmaxf(acc[pt][ct][j] + res[pt][ct][j], 0.f);
                         res[pt][ct][j] = v;
                         o16[j] = (_Float16)v;
                     }
@@ -368,6 +392,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STAMP) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_mark; t_mark = now; }
+    }
+    if constexpr (STAMP) {
+        // per wave: [loop cycles, epilogue cycles, cycles before the first conv, total so far]
+        if (lane == 0 && out) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out) + ((size_t)blockIdx.x * 8 + wave) * 4;
+            dbg[0] = t_loop; dbg[1] = t_epi; dbg[2] = 0; dbg[3] = __builtin_amdgcn_s_memtime() - t_begin;
+        }
+        return;
     }
 
     if (out) {

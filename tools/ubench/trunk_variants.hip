@@ -91,6 +91,28 @@ static Bufs make(int F, int blocks, int boards)
     return b;
 }
 
+template <int F, int NB>
+static void stamps(const Bufs &b, int blocks, int boards)
+{
+    typedef Geo16<F, NB> G;
+    kern_t k = k_trunk_x16<F, NB, 1, 2>;
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    const int nwg = boards / NB;
+    unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)nwg * 8 * 4 * 8));
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(512), G::LDS_BYTES, 0, b.planes, b.wts, b.bias, (float *)dbg, blocks, b.head_w, b.head_b, b.head_out);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)nwg * 32);
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double loop = 0, epi = 0, tot = 0;
+    for (int i = 0; i < nwg * 8; i++) { loop += h[i * 4]; epi += h[i * 4 + 1]; tot += h[i * 4 + 3]; }
+    const int n = nwg * 8, convs = 1 + 2 * blocks;
+    const double mf = (F == 64 ? (4.0 + 2.0 * blocks * 2) : F == 128 ? 4.0 * convs : (4.0 + 2.0 * blocks * 8)) * 9 * (G::PT * G::CT) * 16 * 2;
+    printf("stamps x16<%d,%d>: per wave: main loops %.0f cycles (MFMA-paced minimum at 2 waves/SIMD %.0f), epilogues %.0f (%.0f per conv), "
+           "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, loop / n, mf, epi / n, epi / n / convs, tot / n,
+           loop / tot, epi / tot);
+}
+
 int main(int argc, char **argv)
 {
     const int boards = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -106,6 +128,10 @@ int main(int argc, char **argv)
         run("k_trunk_x16<128,4,1> 16x16x32", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1,1> alt issuer", k_trunk_x16<128, 4, 1, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> again", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        stamps<128, 4>(b, 10, boards);
+        run("  x16<128,4> no staging (timing)", k_trunk_x16<128, 4, 1, 3>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("  x16<128,4> no barrier (timing)", k_trunk_x16<128, 4, 1, 4>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("  x16<128,4> neither (timing)", k_trunk_x16<128, 4, 1, 5>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,2,1> 512 boards", k_trunk_x16<128, 2, 1>, Geo16<128, 2>::LDS_BYTES, 2, 128, 10, 512, reps, b, out, nullptr);
     }
     if (argc > 3 && atoi(argv[3]) == 0) return 0;
@@ -121,6 +147,10 @@ int main(int argc, char **argv)
         run("  VAR 3 registers + late half", k_trunk_gen<256, 2, 1, 3>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1> 16x16x32", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+        stamps<256, 2>(b, 20, boards);
+        run("  x16<256,2> no staging (timing)", k_trunk_x16<256, 2, 1, 3>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+        run("  x16<256,2> no barrier (timing)", k_trunk_x16<256, 2, 1, 4>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+        run("  x16<256,2> neither (timing)", k_trunk_x16<256, 2, 1, 5>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1,1> alt issuer", k_trunk_x16<256, 2, 1, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
     }
     {
