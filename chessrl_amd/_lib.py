@@ -102,7 +102,10 @@ def lib():
     import torch  # noqa: F401
     tuning = os.environ.get("CRL_TUNING_LIB") == "1"
     so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
-    if is_stale(so, extra):
+    override = os.environ.get("CRL_LIB_PATH")          # tools only: A/B an older build of the library
+    if override:
+        so = override
+    elif is_stale(so, extra):
         try:
             build(tuning=tuning)
         except Exception as e:  # pragma: no cover

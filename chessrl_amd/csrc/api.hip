@@ -177,7 +177,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     A(d.rec_moves, G * (size_t)d.MAXPLY); A(d.game_result, G);
     A(d.n_nodes, G); A(d.edge_top, G); A(d.root_visits, G); A(d.root_dead, G);
     AN(d.meta, GN); AN(d.nb1, GN); AN(d.nb2, GN); AN(d.nh1, GN); AN(d.nh2, GN); AN(d.n_reply, GN);
-    AN(d.e_move, GE); AN(d.e_child, GE); AN(d.e_visits, GE); AN(d.e_prior, GE); AN(d.e_value, GE);
+    AN(d.edge, GE);
     A(d.path_len, G); AN(d.path_edge, GN); AN(d.path_node, GN); A(d.leaf_node, G); A(d.leaf_kind, G);
     A(d.s1_moves, G * MAX_MOVES); A(d.s1_n, G);
     A(d.counters, G * CNT_N); A(d.err, 1);
@@ -190,7 +190,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
 #undef AN
     if (!ok) {
         std::string msg = "crl_create: hipMalloc failed (pools need about " +
-                          std::to_string((GE * 20 + GN * 170) >> 20) + " MiB)";
+                          std::to_string((GE * sizeof(Edge) + GN * 170) >> 20) + " MiB)";
         for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, CRL_ERR_HIP, msg);

@@ -175,12 +175,11 @@ __device__ inline void dev_error(const Dev &d, int code)
 __device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, const u16 *mv, int lane)
 {
     for (int j = lane; j < n; j += 64) {
-        size_t e = eb + edge0 + j;
-        d.e_move[e] = mv[j];
-        d.e_child[e] = CHILD_NONE;
-        d.e_visits[e] = 0;
-        d.e_value[e] = 0.0;
-        d.e_prior[e] = 1.0f;                 // Node.prior = 1 (mctree.py:35)
+        Edge e;
+        e.value = 0.0; e.visits = 0;
+        e.prior = 1.0f;                      // Node.prior = 1 (mctree.py:35)
+        e.move = mv[j]; e.child = CHILD_NONE; e.pad = 0;
+        d.edge[eb + edge0 + j] = e;
     }
 }
 
@@ -189,9 +188,9 @@ __device__ inline void gather_priors(const Dev &d, int row, size_t eb, int edge0
 {
     for (int j = lane; j < n; j += 64) {
         size_t e = eb + edge0 + j;
-        int lab = label_of(d, d.e_move[e]);
+        int lab = label_of(d, d.edge[e].move);
         if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
-        d.e_prior[e] = pol[(size_t)row * N_LABELS + lab];
+        d.edge[e].prior = pol[(size_t)row * N_LABELS + lab];
     }
 }
 
@@ -461,9 +460,9 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
     const int plen = d.path_len[g];
     for (int l = lane; l < plen; l += 64) {
-        size_t e = eb + d.path_edge[nb + l];
-        d.e_visits[e] += 1;
-        d.e_value[e] = __dadd_rn(d.e_value[e], v);
+        Edge *e = d.edge + eb + d.path_edge[nb + l];
+        e->visits += 1;
+        e->value = __dadd_rn(e->value, v);
     }
     if (lane == 0) {
         d.root_visits[g] += 1;
@@ -508,7 +507,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
         if (nexp < nmoves) {                                           // not fully expanded
             const int j = nmoves - 1 - nexp;                           // list.pop(): last first
             const int edge = edge0 + j;
-            const u32 mv = d.e_move[eb + edge];
+            const u32 mv = d.edge[eb + edge].move;
             const int c = d.n_nodes[g];
             if (c >= d.N || level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
             if (lane == 0) {
@@ -535,13 +534,13 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
                 if (lane == 0) {
                     d.nb2[nb + c] = e.b;
                     d.nh2[nb + c] = e.hash;
-                    d.e_child[eb + edge] = (u16)(c | CHILD_TERMINAL);
+                    d.edge[eb + edge].child = (u16)(c | CHILD_TERMINAL);
                     d.leaf_kind[g] = LEAF_NEW_S1_OVER;
                 }
             } else {
                 for (int i = lane; i < e.n; i += 64) d.s1_moves[(size_t)g * MAX_MOVES + i] = s.mv[i];
                 if (lane == 0) {
-                    d.e_child[eb + edge] = (u16)c;
+                    d.edge[eb + edge].child = (u16)c;
                     d.s1_n[g] = e.n;
                     d.leaf_kind[g] = LEAF_NEW_REPLY;
                 }
@@ -553,35 +552,34 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
         // ---- get_best_child (mctree.py:89-95): argmax of Q+U, first max in children order,
         // i.e. the LARGEST legal index among equals
         double best = -__builtin_inf();
-        int bj = -1;
+        int bj = -1, bchild = 0;
         for (int base = 0; base < nmoves; base += 64) {
             const int j = base + lane;
             if (j < nmoves) {
-                const size_t e = eb + edge0 + j;
-                const int n = d.e_visits[e];
-                const double w = d.e_value[e];
-                const float pr = d.e_prior[e];
-                const bool term = (d.e_child[e] & CHILD_TERMINAL) != 0;
+                const Edge e = d.edge[eb + edge0 + j];                 // one 24-byte record per lane
+                const int n = e.visits;
+                const bool term = (e.child & CHILD_TERMINAL) != 0;
                 const double den = (double)(1 + n);
-                const double q = __ddiv_rn(w, den);
+                const double q = __ddiv_rn(e.value, den);
                 const double sumv = term ? 0.0 : (double)(n - 1);
-                const double cp = legacy ? __dmul_rn(10.0, (double)pr)
-                                         : (double)__fmul_rn(10.0f, pr);
+                const double cp = legacy ? __dmul_rn(10.0, (double)e.prior)
+                                         : (double)__fmul_rn(10.0f, e.prior);
                 const double u = __dmul_rn(cp, __ddiv_rn(__dsqrt_rn(sumv), den));
                 const double sc = __dadd_rn(q, u);
-                if (bj < 0 || sc > best || (sc == best && j > bj)) { best = sc; bj = j; }
+                if (bj < 0 || sc > best || (sc == best && j > bj)) { best = sc; bj = j; bchild = e.child; }
             }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             const double ob = __shfl_xor(best, o);
             const int oj = __shfl_xor(bj, o);
+            const int oc = __shfl_xor(bchild, o);
             const bool take = oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj));
-            if (take) { best = ob; bj = oj; }
+            if (take) { best = ob; bj = oj; bchild = oc; }
         }
         bj = uni(bj);
         const int edge = edge0 + bj;
-        const int child = d.e_child[eb + edge] & CHILD_NONE;
+        const int child = uni(bchild) & CHILD_NONE;                    // the winner's record held it
         if (level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
         if (lane == 0) {
             d.path_edge[nb + level] = edge;
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
         d.nh2[nb + c] = e.hash;
         d.n_reply[nb + c] = (u16)reply;
         d.edge_top[g] = edge0 + e.n;
-        if (e.result != RESULT_NONE) d.e_child[eb + m.parent_edge] = (u16)(c | CHILD_TERMINAL);
+        if (e.result != RESULT_NONE) d.edge[eb + m.parent_edge].child = (u16)(c | CHILD_TERMINAL);
         d.leaf_kind[g] = LEAF_NEW_S2;
     }
     __syncthreads();
@@ -638,15 +636,15 @@ __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, in
     NodeMeta m = d.meta[nb];
     if (lane == 0) { nchild[r] = m.nexp; root_visits[r] = d.root_visits[g]; }
     for (int k = lane; k < m.nexp; k += 64) {
-        const size_t e = eb + m.edge0 + (m.nmoves - 1 - k);      // children order = reverse legal
+        const Edge e = d.edge[eb + m.edge0 + (m.nmoves - 1 - k)];   // children order = reverse legal
         const size_t o = (size_t)r * MAX_MOVES + k;
-        const int c = d.e_child[e] & CHILD_NONE;
-        visits[o] = d.e_visits[e];
-        values[o] = d.e_value[e];
+        const int c = e.child & CHILD_NONE;
+        visits[o] = e.visits;
+        values[o] = e.value;
         // _update_prior runs only once the node is fully expanded (mctree.py:254-255); until
         // then the reference's children still carry Node.prior = 1
-        priors[o] = m.nexp < m.nmoves ? 1.0f : d.e_prior[e];
-        moves[o] = d.e_move[e];
+        priors[o] = m.nexp < m.nmoves ? 1.0f : e.prior;
+        moves[o] = e.move;
         replies[o] = d.meta[nb + c].has_s2 ? d.n_reply[nb + c] : NO_MOVE;
     }
 }
@@ -661,8 +659,8 @@ __global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u1
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     NodeMeta m = d.meta[nb];
     if (k >= m.nexp || d.leaf_kind[g] != LEAF_NONE) { dev_error(d, DERR_STATE); return; }
-    const size_t e = eb + m.edge0 + (m.nmoves - 1 - k);
-    const int c = d.e_child[e] & CHILD_NONE;
+    const Edge ed = d.edge[eb + m.edge0 + (m.nmoves - 1 - k)];
+    const int c = ed.child & CHILD_NONE;
     NodeMeta cm = d.meta[nb + c];
     const int p = d.ply[g];
     const int np = p + (cm.has_s2 ? 2 : 1);
@@ -670,8 +668,8 @@ __global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u1
     size_t hi = (size_t)g * HIST_RING + ((p + 1) & (HIST_RING - 1));
     d.hist[hi] = d.nb1[nb + c];
     d.hist_hash[hi] = d.nh1[nb + c];
-    d.rec_moves[(size_t)g * d.MAXPLY + p] = d.e_move[e];
-    bm[r] = d.e_move[e];
+    d.rec_moves[(size_t)g * d.MAXPLY + p] = ed.move;
+    bm[r] = ed.move;
     if (cm.has_s2) {
         hi = (size_t)g * HIST_RING + ((p + 2) & (HIST_RING - 1));
         d.hist[hi] = d.nb2[nb + c];

@@ -12,12 +12,13 @@
 //   nodes   meta[G][N]            16-byte record: edge range, expansion cursor, result
 //           nb1/nb2[G][N]         S1 (after our move) / S2 (after the stored reply)
 //           nh1/nh2[G][N]         transposition-key filter hashes of S1 / S2
-//   edges   e_*[G][ECAP]          one slot per LEGAL MOVE of a node, in python-chess
-//                                 order: child's visits (i32), value sum (f64), prior
-//                                 (f32), move (u16), child node id | terminal<<15.
-//                                 A node's children stats are contiguous, so the PUCT
-//                                 scan of get_best_child (mctree.py:89-95) is one
-//                                 coalesced 64-lane read per array.
+//   edges   edge[G][ECAP]         one 24-byte record per LEGAL MOVE of a node, in python-chess
+//                                 order: child's value sum (f64), visits (i32), prior (f32),
+//                                 move (u16), child node id | terminal<<15.  A node's records
+//                                 are contiguous: the PUCT scan of get_best_child
+//                                 (mctree.py:89-95) is one coalesced read of 64 x 24 bytes, the
+//                                 backup's visits/value update touches one sector per level,
+//                                 and the winner's child id comes out of the same record.
 //   step    path_*[G][N]          the selection path of the pending simulation
 #pragma once
 #include "board.hpp"
@@ -51,6 +52,17 @@ struct __attribute__((aligned(16))) NodeMeta {
 };
 static_assert(sizeof(NodeMeta) == 16, "NodeMeta must be 16 bytes");
 
+// One legal move of a node = one child slot (Node.value / visits / prior of mctree.py:28-37).
+struct __attribute__((aligned(8))) Edge {
+    double value;           // child's value sum
+    int32_t visits;         // child's visit count
+    float prior;            // child's prior (1 until the parent is fully expanded)
+    u16 move;               // the move (u16 id)
+    u16 child;              // child node id | CHILD_TERMINAL, CHILD_NONE while unexpanded
+    uint32_t pad;
+};
+static_assert(sizeof(Edge) == 24, "Edge must be 24 bytes");
+
 enum Counter { CNT_SIMS = 0, CNT_NODES, CNT_DEPTH, CNT_BRANCH, CNT_EVALS, CNT_TERMINAL, CNT_N };
 
 struct Dev {
@@ -72,10 +84,7 @@ struct Dev {
     Board *nb1, *nb2;
     u64 *nh1, *nh2;
     u16 *n_reply;
-    u16 *e_move, *e_child;
-    int32_t *e_visits;
-    float *e_prior;
-    double *e_value;
+    Edge *edge;
     // pending simulation
     int32_t *path_len, *path_edge, *leaf_node;
     u16 *path_node;

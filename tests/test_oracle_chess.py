@@ -104,3 +104,24 @@ def test_position_with_the_maximum_number_of_legal_moves():
     lm = g.get_legal_moves()
     assert len(lm) == 218 and len(set(lm)) == 218
     assert g.get_result() is None
+
+
+def test_python_chess_readme_known_answers():
+    """The python-chess README's own worked examples (public known answers of the package the
+    reference delegates to, requirements.txt:9): scholar's mate -- `board.is_checkmate()` True after
+    e4 e5 Qh5 Nc6 Bc4 Nf6 Qxf7#; and, for that final position given as a FEN, `is_stalemate()`
+    False, `is_insufficient_material()` False, `is_game_over()` True, `can_claim_fifty_moves()`
+    False, `halfmove_clock` 0, `is_fivefold_repetition()` False, `is_seventyfive_moves()` False."""
+    g = OracleGame()
+    for u in ["e2e4", "e7e5", "d1h5", "b8c6", "f1c4", "g8f6"]:
+        assert g.move(u) and g.get_result() is None
+    assert g.move("h5f7")
+    assert g.get_result() == 1 and g.get_legal_moves() == []            # checkmate, white won
+    fen = "r1bqkb1r/pppp1Qpp/2n2n2/4p3/2B1P3/8/PPPP1PPP/RNB1K1NR b KQkq - 0 4"
+    h = OracleGame(board=board_from_fen(fen))
+    assert h.get_fen() == g.get_fen() == fen.split()[0]
+    assert h.get_result() == 1 and h.repetitions() == 1
+    assert (g.board_at(0).state >> 12) & 255 == 0                       # the capture reset the clock
+    # README "Make and unmake moves": Nf3 is legal at the start, a8a1 is not
+    s = OracleGame()
+    assert "g1f3" in s.get_legal_moves() and not s.move("a8a1") and len(s.get_legal_moves()) == 20

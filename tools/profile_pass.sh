@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-2 profile passes on the GPU box (run through gpurun).  Writes raw rocprofv3 output under
+# gpurun_out/prof_r02/ and the distilled per-kernel numbers to gpurun_out/prof_r02/summary.json.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r02
+mkdir -p $O
+pmc() {   # name counter cmd...
+  local name=$1 ctr=$2; shift 2
+  rm -rf /tmp/pm_$name
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pm_$name -- "$@" > /dev/null 2>&1
+  find /tmp/pm_$name -name "*counter_collection.csv" -exec cp {} $O/${name}_${ctr}.csv \;
+}
+pmc trunk128 FETCH_SIZE python3 $R/tools/trunk_once.py 10 128 4096
+pmc trunk128 WRITE_SIZE python3 $R/tools/trunk_once.py 10 128 4096
+pmc trunk256 FETCH_SIZE python3 $R/tools/trunk_once.py 20 256 4096
+pmc trunk256 WRITE_SIZE python3 $R/tools/trunk_once.py 20 256 4096
+pmc trunk64 FETCH_SIZE python3 $R/tools/trunk_once.py 6 64 512
+pmc trunk64 WRITE_SIZE python3 $R/tools/trunk_once.py 6 64 512
+pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1
+pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1
+for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
+  set -- $cfg; name=$1; shift
+  rm -rf /tmp/st_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
+  find /tmp/st_$name -name "*kernel_stats.csv" -exec cp {} $O/bench_${name}_kernel_stats.csv \;
+  find /tmp/st_$name -name "*domain_stats.csv" -exec cp {} $O/bench_${name}_domain_stats.csv \;
+done
+ls -la $O

@@ -1,13 +1,20 @@
-"""Scratch (GPU): run the fused trunk a few times (for rocprofv3 --pmc)."""
-import sys, os
+"""Scratch (GPU): a few launches of the production fused trunk from plane bitboards, for rocprofv3
+passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--kernel-trace --stats`).
+python tools/trunk_once.py [blocks=10] [filters=128] [boards=4096]"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from chessrl_amd.model import ChessModel
-B = 4096
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+filters = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 rng = np.random.default_rng(0)
-x = torch.zeros((B, 8, 8, 128), dtype=torch.float16, device="cuda:0")
-x[..., :127] = torch.from_numpy((rng.random((B, 8, 8, 127)) < 0.12).astype(np.float16)).cuda()
-m = ChessModel(blocks=10, filters=128)
+bits = torch.from_numpy(rng.integers(0, 1 << 62, (B, 128), dtype=np.int64) &
+                        rng.integers(0, 1 << 62, (B, 128), dtype=np.int64) &
+                        rng.integers(0, 1 << 62, (B, 128), dtype=np.int64)).cuda()     # ~12 % of the bits set
+bits[:, 127] = 0
+m = ChessModel(blocks=blocks, filters=filters)
 for _ in range(3):
-    m._run_fused(x)
+    m._run_fused(bits)
 torch.cuda.synchronize()
