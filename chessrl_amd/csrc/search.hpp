@@ -442,11 +442,11 @@ __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
 __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, const float *pol2,
                                       const float *val2)
 {
-    const int kind = d.leaf_kind[g];
+    const int kind = uni(d.leaf_kind[g]);
     if (kind == LEAF_NONE) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     if (kind == LEAF_NEW_REPLY) { dev_error(d, DERR_STATE); return; }
-    const int leaf = d.leaf_node[g];
+    const int leaf = uni(d.leaf_node[g]);
     NodeMeta m = d.meta[nb + leaf];
     double v;
     unsigned long long evals = 0;
@@ -458,7 +458,7 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
         evals = 1;                                     // policy/value(S2)
     }
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
-    const int plen = d.path_len[g];
+    const int plen = uni(d.path_len[g]);
     for (int l = lane; l < plen; l += 64) {
         Edge *e = d.edge + eb + d.path_edge[nb + l];
         e->visits += 1;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
 
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     const bool legacy = (d.flags & 1u) != 0;
-    const int p = d.ply[g];
+    const int p = uni(d.ply[g]);
     int node = 0, level = 0;
     for (;;) {
         NodeMeta m = d.meta[nb + node];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
             const int j = nmoves - 1 - nexp;                           // list.pop(): last first
             const int edge = edge0 + j;
             const u32 mv = d.edge[eb + edge].move;
-            const int c = d.n_nodes[g];
+            const int c = uni(d.n_nodes[g]);                           // wave-uniform: scalar addressing
             if (c >= d.N || level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
             if (lane == 0) {
                 d.meta[nb + node].nexp = (u16)(nexp + 1);
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.root_dead[g] || d.leaf_kind[g] != LEAF_NEW_REPLY) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
-    const int c = d.leaf_node[g], level = d.path_len[g], n1 = d.s1_n[g], p = d.ply[g];
+    const int c = uni(d.leaf_node[g]), level = uni(d.path_len[g]), n1 = uni(d.s1_n[g]), p = uni(d.ply[g]);
     Board s1 = d.nb1[nb + c];
     // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
     const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
     const u32 reply = mv1[bi];
     Board s2 = apply_move(s1, reply);
     PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);
-    const int edge0 = d.edge_top[g];
+    const int edge0 = uni(d.edge_top[g]);
     if (edge0 + e.n > d.ECAP) { dev_error(d, DERR_EDGE_POOL); return; }
     init_edges(d, eb, edge0, e.n, s.mv, lane);
     if (lane == 0) {

@@ -1,0 +1,62 @@
+"""Turn the raw rocprofv3 output of tools/profile_pass.sh (gpurun_out/prof_r02/) into the tracked
+evidence: profiles/r02/*.csv (kernel stats as rocprofv3 wrote them), profiles/r02/pmc_summary.json
+and the PMC table bench.py reads (profiles/pmc_traffic.json).  python tools/distill_profiles.py"""
+import collections
+import csv
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+DST = os.path.join(ROOT, "profiles", "r02")
+os.makedirs(DST, exist_ok=True)
+
+
+def per_kernel(path, last=None):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[name].append(float(r["Counter_Value"]))
+    return {k: (sum(v[-last:] if last else v) / len(v[-last:] if last else v), len(v)) for k, v in acc.items()}
+
+
+passes, summary = [], {}
+shapes = {"trunk128": "4096 boards, 10 blocks x 128 filters", "trunk256": "4096 boards, 20 blocks x 256 filters",
+          "trunk64": "512 boards, 6 blocks x 64 filters"}
+for tag, shape in shapes.items():
+    f = per_kernel(os.path.join(SRC, tag + "_FETCH_SIZE.csv"))
+    w = per_kernel(os.path.join(SRC, tag + "_WRITE_SIZE.csv"))
+    for k in f:
+        if "k_trunk" not in k:
+            continue
+        short = k.split("::")[-1]
+        short = short[:short.rindex(",")] + ">"               # drop the ALT template argument (0)
+        passes.append({"kernel": short, "shape": shape, "fetch_size_kb": round(f[k][0], 1),
+                       "write_size_kb": round(w[k][0], 1),
+                       "source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc, tools/trunk_once.py, %d launches)" % f[k][1]})
+        summary[short + " @ " + shape] = {"FETCH_SIZE_KB": f[k][0], "WRITE_SIZE_KB": w[k][0]}
+tf = per_kernel(os.path.join(SRC, "tree_FETCH_SIZE.csv"), last=50)
+tw = per_kernel(os.path.join(SRC, "tree_WRITE_SIZE.csv"), last=50)
+tree = {k.split("::")[-1]: {"FETCH_SIZE_KB": tf[k][0], "WRITE_SIZE_KB": tw[k][0], "launches": tf[k][1]}
+        for k in tf if "k_select_expand" in k or "k_reply" in k}
+shape_file = os.path.join(SRC, "tree_shape.json")
+tree_shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {}
+summary["search kernels, 4096 games, bit planes (mean of the last 50 launches)"] = dict(tree, tree=tree_shape)
+passes.append({"kernel": "k_select_expand + k_reply", "shape": "4096 games, bit planes",
+               "fetch_size_kb": round(sum(v["FETCH_SIZE_KB"] for v in tree.values()), 1),
+               "write_size_kb": round(sum(v["WRITE_SIZE_KB"] for v in tree.values()), 1),
+               "source": "profiles/r02/pmc_summary.json (tools/tree_once.py 4096 400 1, last 50 launches; %s)" % json.dumps(tree_shape)})
+json.dump(summary, open(os.path.join(DST, "pmc_summary.json"), "w"), indent=1)
+table = {"what": "HBM-side traffic per launch from rocprofv3 PMC passes (one counter per pass; FETCH_SIZE and "
+                 "WRITE_SIZE in KB as rocprofv3 reports them; bench.py applies the gfx950 x2 wide-read correction to "
+                 "FETCH_SIZE). Keyed by the kernel name rocprofv3 prints (without the trailing diagnostic template "
+                 "argument) and the launch shape; bench.py emits traffic only for an exact match.",
+         "passes": passes}
+json.dump(table, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+for n in ("c3", "c5", "c2"):
+    for kind in ("kernel_stats.csv", "domain_stats.csv", "profiled.json"):
+        src = os.path.join(SRC, "bench_%s_%s" % (n, kind))
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, "bench_%s_%s" % (n, kind)))
+print(json.dumps(summary, indent=1))

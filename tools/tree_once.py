@@ -30,4 +30,9 @@ for _ in range(steps):
     eng.step()
 torch.cuda.synchronize()
 c = eng.ctx.counters()
+if len(sys.argv) > 4:          # the tree shape the passes saw, for the PMC table
+    import json
+    c0 = dict(c)
+    json.dump({"games": G, "steps": steps, "mean_depth_all": c["depth_sum"] / max(1, c["sims"]),
+               "mean_branch": c["branch_sum"] / max(1, c["nodes"])}, open(sys.argv[4], "w"))
 print({k: int(v) for k, v in c.items()}, "depth", c["depth_sum"] / max(1, c["sims"]), "branch", c["branch_sum"] / max(1, c["nodes"]))
