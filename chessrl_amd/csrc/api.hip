@@ -633,8 +633,6 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         case 216: kern = crl_tower::k_trunk128_pipe<16>; break;                // x reads for dx = 0 only
         case 232: kern = crl_tower::k_trunk128_pipe<32>; break;                // no vmcnt wait for the DMA
         case 234: kern = crl_tower::k_trunk128_pipe<34>; break;                // ... and no barrier
-        case 264: kern = crl_tower::k_trunk128_pipe<64>; break;                // weights via registers
-        case 328: kern = crl_tower::k_trunk128_pipe<128>; break;               // waves 4-7 half a step late
         case 300: CRL_GEN(128, 4); break;                                      // the template at F = 128
         default: kern = crl_tower::k_trunk_x16<128, 4, 0>; lds_bytes = crl_tower::Geo16<128, 4>::LDS_BYTES; break;
         }

@@ -1,4 +1,6 @@
-// tower_gen.hpp -- the production trunk structure of tower_pipe.hpp (LDS-resident boards, fp32
+// tower_gen.hpp -- ROUND-1 kernels for 64 / 256 filters and small batches (32x32x16 MFMA); since
+// round 2 dispatched only by the tuning library (the product runs tower_x16.hpp, which reuses the
+// helpers here).  The trunk structure of tower_pipe.hpp (LDS-resident boards, fp32
 // residual stream in registers, 4-deep LDS-DMA weight ring, pinned hand-counted software pipeline,
 // padded activation rows, conflict-free zero rows, head convs in the tail) templated on the number
 // of filters F in {64, 128, 256}: every tower size of BASELINE.json (C2 6x64, C3/C4 10x128, C5
@@ -46,7 +48,6 @@ struct Geo {
     static constexpr int WRING_OFF = ((BIAS_OFF + F * 4 + 1023) / 1024) * 1024;
     static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static constexpr int lds_bytes(int ring) { return WRING_OFF + ring * TILE_BYTES; }
     // swizzle of a weight-tile row: XOR of the chunk index with row bits that differ inside a
     // ds_read_b128 lane group, so 16 lanes cover all 64 banks
     __device__ static int wswz(int row) { return WCH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
@@ -61,57 +62,27 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 }
 
 template <class G>
-__device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, int t, int tid, int slot = -1)
+__device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, int t, int tid)
 {
     const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
-    lds_byte *dst = lds + G::WRING_OFF + (slot < 0 ? (t & (PIPE_RING - 1)) : slot) * G::TILE_BYTES;
+    lds_byte *dst = lds + G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
     const int wave_base = tid & ~63;
 #pragma unroll
     for (int j = 0; j < G::GL; j++) {
         const int idx = j * 512 + tid;                  // 16-B slot of the tile image
         const int row = idx / G::WCH, phys = idx % G::WCH;
         const int chunk = phys ^ G::wswz(row);
-        // uniform 64-bit base + unsigned 32-bit lane offset: the SGPR-base form of the load (one
-        // VGPR of address instead of a 64-bit VALU add per piece)
-        const unsigned off = (unsigned)(row * G::WROW + chunk * 16);
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(src + off),
+            (const __attribute__((address_space(1))) void *)(src + row * G::WROW + chunk * 16),
             (__attribute__((address_space(3))) void *)(dst + (j * 512 + wave_base) * 16), 16, 0, 0);
     }
 }
 
-// the same tile through registers (global_load_dwordx4 now, ds_write_b128 one tile-step later)
-template <class G>
-__device__ __forceinline__ void wtile_to_regs_gen(const unsigned char *wts, int t, int tid, u32x4 (&wreg)[G::GL])
-{
-    const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < G::GL; j++) {
-        const int idx = j * 512 + tid;
-        const int row = idx / G::WCH, phys = idx % G::WCH;
-        const int chunk = phys ^ G::wswz(row);
-        wreg[j] = *reinterpret_cast<const u32x4 *>(src + row * G::WROW + chunk * 16);
-    }
-}
-template <class G>
-__device__ __forceinline__ void regs_to_wring_gen(lds_byte *lds, int t, int tid, const u32x4 (&wreg)[G::GL])
-{
-    lds_byte *dst = lds + G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < G::GL; j++)
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst + (j * 512 + tid) * 16) = wreg[j];
-}
-
-// VAR (results identical in every variant): bit 0 = weight tiles through registers instead of
-// LDS-DMA; bit 1 = waves 4-7 meet the per-tile barrier half a tile-step after waves 0-3 did, i.e.
-// the two waves of a SIMD alternate between their MFMA burst and their barrier / staging work
-// (MI355X_MICROARCH.md, two waves per SIMD, item 9); bit 2 = one barrier per TWO tiles over a
-// five-tile ring (SPT = 2 only: 256 filters).
 //   planes  fp16 [n_boards][64][128]
 //   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
-template <int F, int NB, int BITS = 0, int VAR = 0>
+template <int F, int NB, int BITS = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -134,24 +105,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
     const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
-    constexpr bool REGSTAGE = (VAR & 1) != 0, STAGGER = (VAR & 2) != 0, PAIR = (VAR & 4) != 0;
-    static_assert(!PAIR || (G::SPT == 2 && !REGSTAGE), "pair publishing is written for two sub-steps per tile");
-    constexpr int RING = PAIR ? 5 : PIPE_RING;
-    static_assert(G::lds_bytes(RING) <= 160 * 1024, "LDS budget");
-    const bool late_half = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
-    u32x4 wreg[G::GL];                                  // REGSTAGE: the tile on its way to LDS
-    int slot_t = 0;                                     // PAIR: ring slot of tile t (t mod 5, kept incrementally)
-    auto slot_add = [](int s, int k) { const int x = s + k; return x >= 5 ? x - 5 : x; };
 
-    if constexpr (REGSTAGE) {
-        wtile_to_regs_gen<G>(wts, 0, tid, wreg);
-        regs_to_wring_gen<G>(lds, 0, tid, wreg);
-        wtile_to_regs_gen<G>(wts, 1, tid, wreg);
-    } else {
-        stage_wtile_gen<G>(wts, lds, 0, tid, PAIR ? 0 : -1);
-        stage_wtile_gen<G>(wts, lds, 1, tid, PAIR ? 1 : -1);
-        stage_wtile_gen<G>(wts, lds, 2, tid, PAIR ? 2 : -1);
-    }
+    stage_wtile_gen<G>(wts, lds, 0, tid);
+    stage_wtile_gen<G>(wts, lds, 1, tid);
+    stage_wtile_gen<G>(wts, lds, 2, tid);
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
         if constexpr (BITS) {
@@ -171,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =
                 u32x4{0u, 0u, 0u, 0u};
     }
-    if constexpr (!REGSTAGE) wait_vmcnt<2 * G::GL>();   // tile 0 landed (tiles 1,2 may be in flight)
+    wait_vmcnt<2 * G::GL>();                            // tile 0 landed (tiles 1,2 may be in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -235,30 +192,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                 const int tile = next_tap ? t_tap0 + NS / G::SPT : t_tap0 + i / G::SPT;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) f.x[mt] = lds_read16_asm<i * 32>(ab[next_tap ? 1 : 0][mt]);
-                // PAIR: the fragments fetched are those of tile t (the one being computed) or t+1
-                const int slot = PAIR ? (tile == t ? slot_t : slot_add(slot_t, 1)) : (tile & (PIPE_RING - 1));
-                const int wb = lds_base + G::WRING_OFF + slot * G::TILE_BYTES;
+                const int wb = lds_base + G::WRING_OFF + (tile & (PIPE_RING - 1)) * G::TILE_BYTES;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) f.w[nt] = lds_read16_asm<0>(wb + waddr[nt][i % G::SPT]);
             };
-            // once per tile t (PAIR: per two tiles): publish the next tile(s), recycle dead slots
-            auto tile_sync = [&]() {
-                if constexpr (REGSTAGE) {
-                    if (t + 1 < n_tiles) regs_to_wring_gen<G>(lds, t + 1, tid, wreg);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (t + 2 < n_tiles) wtile_to_regs_gen<G>(wts, t + 2, tid, wreg);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else if constexpr (PAIR) {
-                    // before the last sub-step of an even tile t: until the next sync a wave reads
-                    // tiles t, t+1, t+2 (all landed: issued at the previous sync) -- tiles < t are dead
-                    wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (t + 3 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 3, tid, slot_add(slot_t, 3));
-                    if (t + 4 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 4, tid, slot_add(slot_t, 4));
-                } else {
+            if (tap == 0) fetch(std::integral_constant<int, 0>{}, false, f0);
+            static_for<0, NS>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                constexpr int s = i % G::SPT;
+                if constexpr (s == G::SPT - 1 - (G::SPT > 2 ? 1 : 0)) {
                     // publish tile t+1 before the sub-step that prefetches its first fragments
                     // (SPT = 4: before sub-step 2; SPT = 2: before sub-step 1); recycle tile t-1's slot
                     if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
@@ -266,21 +208,6 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     if (t + 3 < n_tiles) stage_wtile_gen<G>(wts, lds, t + 3, tid);
-                }
-            };
-            if (tap == 0) fetch(std::integral_constant<int, 0>{}, false, f0);
-            static_for<0, NS>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                constexpr int s = i % G::SPT;
-                constexpr int s_early = G::SPT - 1 - (G::SPT > 2 ? 1 : 0);
-                constexpr int s_late = (s_early + G::SPT / 2) % G::SPT;
-                constexpr bool sync_tile = !PAIR || ((i / G::SPT) % 2 == 0);
-                if constexpr (sync_tile && s == s_early) {
-                    if constexpr (STAGGER) { if (!late_half) tile_sync(); }
-                    else tile_sync();
-                }
-                if constexpr (STAGGER && sync_tile && s == s_late) {
-                    if (late_half) tile_sync();
                 }
                 constexpr bool wrap = i + 1 >= NS;
                 bool issued = false;
@@ -303,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_gen(const unsigned char *__res
                 if constexpr (i % 2 == 0) mfma_all(f0);
                 else mfma_all(f1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s == G::SPT - 1) { t++; if constexpr (PAIR) slot_t = slot_add(slot_t, 1); }
+                if constexpr (s == G::SPT - 1) t++;
             });
         };
 

@@ -1,9 +1,11 @@
 // tower_pipe.hpp -- PRODUCTION build of the fused residual trunk (128 filters) for gfx950.
 //
-// Design: tower_common.hpp (read its header first: LDS-resident boards, fp32 residual stream in
+// ROUND-1 PRODUCTION (32x32x16 MFMA), since round 2 compiled for dispatch only in the tuning library:
+// the product runs tower_x16.hpp, which reuses this file's helpers (static_for, inline-asm LDS
+// reads, plane expansion).  Design: tower_common.hpp (LDS-resident boards, fp32 residual stream in
 // registers, LDS-DMA weight ring, transposed product, in-place epilogue).  tower.hpp is the first,
-// straightforward build of it (tuning library only), the baseline of the ladder in
-// profiles/r01/pmc_trunk_kernel.md; results are bit-identical to it.  Its rocprofv3 counters
+// straightforward build of it, the baseline of the ladder in profiles/r01/pmc_trunk_kernel.md;
+// results are bit-identical to it.  Its rocprofv3 counters
 // at the C3 shape showed the matrix pipe 51 % busy, waves parked in s_waitcnt/s_barrier 38 % of
 // their cycles, ~4 VALU instructions per MFMA, the LDS array 39 % busy with 18 % conflicts.  What
 // this build changes, in the order it paid:
@@ -100,42 +102,16 @@ __device__ inline void stage_wtile_p2(const unsigned char *wts, lds_byte *lds, i
         const int idx = j * 512 + tid;
         const int row = idx >> 3, phys = idx & 7;
         const int chunk = phys ^ ((row >> 1) & 7);
-        const unsigned off = (unsigned)(row * 128 + chunk * 16);   // SGPR base + 32-bit lane offset
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(src + off),
+            (const __attribute__((address_space(1))) void *)(src + row * 128 + chunk * 16),
             (__attribute__((address_space(3))) void *)(dst + (j * 512 + wave_base) * 16), 16, 0, 0);
     }
-}
-
-// Weight tile t through registers instead of LDS-DMA: the same LDS image (lane idx = j*512 + tid
-// owns the 16-byte slot idx of the tile; its source chunk carries the XOR swizzle).
-__device__ __forceinline__ void wtile_to_regs(const unsigned char *wts, int t, int tid, u32x4 (&wreg)[2])
-{
-    const unsigned char *src = wts + (size_t)t * WTILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int idx = j * 512 + tid;
-        const int row = idx >> 3, phys = idx & 7;
-        const int chunk = phys ^ ((row >> 1) & 7);
-        wreg[j] = *reinterpret_cast<const u32x4 *>(src + row * 128 + chunk * 16);
-    }
-}
-__device__ __forceinline__ void regs_to_wring(lds_byte *lds, int t, int tid, const u32x4 (&wreg)[2])
-{
-    lds_byte *dst = lds + P2_WRING_OFF + (t & (PIPE_RING - 1)) * WTILE_BYTES;
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst + (j * 512 + tid) * 16) = wreg[j];
 }
 
 // DIAG = 0: production.  Timing-only builds (WRONG results): bit 0 = no weight staging in the loop,
 // bit 1 = no per-tile barrier, bit 4 (16) = activation fragments read for the dx = 0 taps only (what a
 // cross-lane generation of the dx = +-1 fragments would leave).  Bit 2 (correct results) = staggered staging: waves 0-3 stage at the
 // mid-step barrier, waves 4-7 half a K-step later (measured 2 % slower than staging together).
-// Correct-result experiments: bit 6 (64) = weight tiles staged through registers (global_load_dwordx4,
-// ds_write_b128 one K-step later) instead of LDS-DMA; bit 7 (128) = waves 4-7 meet the per-tile
-// barrier at the START of a K-step instead of its middle, i.e. run half a K-step behind waves 0-3
-// (MI355X_MICROARCH.md, two waves per SIMD, item 9).
 // BITS = 1: `planes` holds 128 plane bitboards per board (expand_bitplanes) instead of fp16 planes.
 template <int DIAG = 0, int BITS = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *__restrict__ planes,
@@ -147,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                                                            float *__restrict__ head_out)
 {
 #ifndef CRL_TUNING
-    static_assert((DIAG & ~(64 | 128)) == 0, "timing-only variants exist in the tuning library only");
+    static_assert(DIAG == 0, "timing-only variants exist in the tuning library only");
 #endif
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
@@ -159,20 +135,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
     const int n_tiles = n_convs * KSTEPS_PER_CONV;
     const size_t wg_board0 = (size_t)blockIdx.x * BOARDS_PER_WG;
 
-    constexpr bool REGSTAGE = (DIAG & 64) != 0, STAGGER = (DIAG & 128) != 0;
-    // waves 4-7: barrier at the start of a K-step (wave-uniform, kept in an SGPR)
-    const bool late_half = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
-    u32x4 wreg[2];                                        // REGSTAGE: the tile on its way to LDS
     // ---- weight stream prologue: three tiles in flight ---------------------------------------------
-    if constexpr (REGSTAGE) {
-        wtile_to_regs(wts, 0, tid, wreg);
-        regs_to_wring(lds, 0, tid, wreg);
-        wtile_to_regs(wts, 1, tid, wreg);                 // written to the ring at the first barrier
-    } else {
-        stage_wtile_p2(wts, lds, 0, tid);
-        stage_wtile_p2(wts, lds, 1, tid);
-        stage_wtile_p2(wts, lds, 2, tid);
-    }
+    stage_wtile_p2(wts, lds, 0, tid);
+    stage_wtile_p2(wts, lds, 1, tid);
+    stage_wtile_p2(wts, lds, 2, tid);
 
     // ---- planes -> padded LDS image; zero rows; biases -------------------------------------------------
     {
@@ -196,8 +162,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             *reinterpret_cast<__attribute__((address_space(3))) float *>(lds + P2_BIAS_OFF + i * 4) = bias[i];
     }
     // tile 0 landed (tiles 1,2 may be in flight), planes/bias/zero rows written: publish
-    if constexpr (REGSTAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -277,21 +242,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
             if (blk == 0) fetch(std::integral_constant<int, 0>{}, 0, false, f0);
             static_for<0, 24>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
-                // once per K-step t: publish tile t+1 (its first read is issued one sub-step before
-                // its K-step starts), recycle the buffer of tile t-1 for tile t+3.  Waves 0-3 (all
-                // waves without STAGGER) do it in the middle of the K-step, the late half at its start.
-                auto tile_sync = [&]() {
-                    if constexpr (REGSTAGE) {
-                        // tile t+1 sits in wreg since the previous sync: park it in its ring slot
-                        // (tile t-3's, dead for two barriers), publish, fetch tile t+2
-                        if (t + 1 < n_tiles) regs_to_wring(lds, t + 1, tid, wreg);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (t + 2 < n_tiles) wtile_to_regs(wts, t + 2, tid, wreg);
-                        __builtin_amdgcn_sched_barrier(0);
-                        return;
-                    }
+                if constexpr ((i & 3) == 2) {
+                    // middle of K-step t: publish tile t+1 (its first read is issued one sub-step
+                    // before its K-step starts), recycle the buffer of tile t-1 for tile t+3
                     if (!(DIAG & 32)) {                  // DIAG 32 (timing only): do not wait for the DMA
                         if (t + 2 < n_tiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,13 +253,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk128_pipe(const unsigned char *_
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(DIAG & 1) && t + 3 < n_tiles && (!(DIAG & 4) || wave < 4))
                         stage_wtile_p2(wts, lds, t + 3, tid);
-                };
-                if constexpr ((i & 3) == 2) {
-                    if constexpr (STAGGER) { if (!late_half) tile_sync(); }
-                    else tile_sync();
                 }
                 if constexpr ((i & 3) == 0) {
-                    if constexpr (STAGGER) { if (late_half) tile_sync(); }
                     if (!(DIAG & 1) && (DIAG & 4) && wave >= 4 && t > 0 && t + 2 < n_tiles)
                         stage_wtile_p2(wts, lds, t + 2, tid);
                 }

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                                                        const float *__restrict__ head_b,
                                                        float *__restrict__ head_out)
 {
+#if !defined(CRL_TUNING) && !defined(CRL_HARNESS)
+    static_assert(ALT == 0, "diagnostic variants are for tools/ubench/trunk_variants.hip only");
+#endif
     typedef Geo16<F, NB> G;
     constexpr int PT = G::PT, CT = G::CT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     constexpr int HP = PT / 2;                          // position blocks per half sub-step
 
     constexpr bool STAMP = ALT == 2;                    // harness diagnostic: in-kernel cycle stamps
-    unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0;
+    unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0, t_ba = 0, t_wr = 0;
     if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); t_mark = t_begin; }
     int t = 0;                                          // tile of the K-step being computed
     for (int conv = 0; conv < n_convs; conv++) {
@@ -358,38 +361,56 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // all reads of the activation buffer done
         __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t_a = 0;
+        if constexpr (STAMP) { t_a = __builtin_amdgcn_s_memtime(); t_ba += t_a - t_mark; }
         // three wave-uniform shapes (branches, not selects: every VALU instruction competes with the
         // partner wave's MFMAs for issue slots): stem = linear (no BN, no activation,
         // model.py:33-34); conv1 = ReLU, skip stream untouched; conv2 = + skip, ReLU, new skip
         const int kind = conv == 0 ? 0 : ((conv & 1) ? 1 : 2);
+        auto store_block = [&](int pt, int ct, const half4 &o16) {
+            *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
+                lds + act_row0 + pt * 16 * G::AROW + (obase + 16 * ct + 4 * q) * 2) = o16;
+        };
+        if (kind == 1) {                                // conv1 of a block: ReLU, skip stream untouched
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const int o0 = obase + 16 * ct + 4 * q;     // 4 consecutive channels
+            for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-            for (int pt = 0; pt < PT; pt++) {
-                half4 o16;
-                if (kind == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        res[pt][ct][j] = acc[pt][ct][j];
-                        o16[j] = (_Float16)acc[pt][ct][j];
-                    }
-                } else if (kind == 1) {
+                for (int pt = 0; pt < PT; pt++) {
+                    half4 o16;
 #pragma unroll
                     for (int j = 0; j < 4; j++) o16[j] = (_Float16)fmaxf(acc[pt][ct][j], 0.f);
-                } else {
+                    store_block(pt, ct, o16);
+                }
+        } else if (kind == 2) {                         // conv2: + skip, ReLU, new skip
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) {
+                    half4 o16;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const float v = fmaxf(acc[pt][ct][j] + res[pt][ct][j], 0.f);
                         res[pt][ct][j] = v;
                         o16[j] = (_Float16)v;
                     }
+                    store_block(pt, ct, o16);
                 }
-                *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
-                    lds + act_row0 + pt * 16 * G::AROW + o0 * 2) = o16;
-            }
+        } else {                                        // stem: linear
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) {
+                    half4 o16;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        res[pt][ct][j] = acc[pt][ct][j];
+                        o16[j] = (_Float16)acc[pt][ct][j];
+                    }
+                    store_block(pt, ct, o16);
+                }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (STAMP) t_wr += __builtin_amdgcn_s_memtime() - t_a;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAMP) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_mark; t_mark = now; }
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         // per wave: [loop cycles, epilogue cycles, cycles before the first conv, total so far]
         if (lane == 0 && out) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out) + ((size_t)blockIdx.x * 8 + wave) * 4;
-            dbg[0] = t_loop; dbg[1] = t_epi; dbg[2] = 0; dbg[3] = __builtin_amdgcn_s_memtime() - t_begin;
+            dbg[0] = t_loop; dbg[1] = t_epi; dbg[2] = (t_ba << 32) | (t_wr & 0xffffffffull); dbg[3] = __builtin_amdgcn_s_memtime() - t_begin;
         }
         return;
     }

@@ -2,6 +2,7 @@
 // check that their outputs are bit-identical.  hipcc --offload-arch=gfx950 -O3 -std=c++17
 // -ffp-contract=off -I chessrl_amd/csrc tools/ubench/trunk_variants.hip -o tools/ubench/trunk_variants
 //   ./trunk_variants [boards=4096] [reps=20]
+#define CRL_HARNESS 1
 #include "tower_pipe.hpp"
 #include "tower_gen.hpp"
 #include "tower_x16.hpp"
@@ -104,13 +105,15 @@ static void stamps(const Bufs &b, int blocks, int boards)
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)nwg * 32);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double loop = 0, epi = 0, tot = 0;
-    for (int i = 0; i < nwg * 8; i++) { loop += h[i * 4]; epi += h[i * 4 + 1]; tot += h[i * 4 + 3]; }
+    double loop = 0, epi = 0, tot = 0, ba = 0, wr = 0;
+    for (int i = 0; i < nwg * 8; i++) { loop += h[i * 4]; epi += h[i * 4 + 1]; tot += h[i * 4 + 3]; ba += (double)(h[i * 4 + 2] >> 32); wr += (double)(h[i * 4 + 2] & 0xffffffffull); }
     const int n = nwg * 8, convs = 1 + 2 * blocks;
     const double mf = (F == 64 ? (4.0 + 2.0 * blocks * 2) : F == 128 ? 4.0 * convs : (4.0 + 2.0 * blocks * 8)) * 9 * (G::PT * G::CT) * 16 * 2;
     printf("stamps x16<%d,%d>: per wave: main loops %.0f cycles (MFMA-paced minimum at 2 waves/SIMD %.0f), epilogues %.0f (%.0f per conv), "
            "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, loop / n, mf, epi / n, epi / n / convs, tot / n,
            loop / tot, epi / tot);
+    printf("   epilogue phases per conv: wait at the first barrier %.0f, convert + LDS writes %.0f, second barrier %.0f cycles\n",
+           ba / n / convs, wr / n / convs, (epi - ba - wr) / n / convs);
 }
 
 int main(int argc, char **argv)
@@ -121,9 +124,6 @@ int main(int argc, char **argv)
         Bufs b = make(128, 10, boards);
         printf("== 10 x 128, %d boards\n", boards);
         run("k_trunk128_pipe<0,1> production", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, ref, nullptr);
-        run("  <64,1> weights via registers", k_trunk128_pipe<64, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
-        run("  <128,1> waves 4-7 half a step late", k_trunk128_pipe<128, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
-        run("  <192,1> both", k_trunk128_pipe<192, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk128_pipe<0,1> again", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> 16x16x32", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1,1> alt issuer", k_trunk_x16<128, 4, 1, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
@@ -139,13 +139,8 @@ int main(int argc, char **argv)
         Bufs b = make(256, 20, boards);
         printf("== 20 x 256, %d boards\n", boards);
         typedef Geo<256, 2> G;
-        run("k_trunk_gen<256,2,1> production", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, ref, nullptr);
-        run("  VAR 2 waves 4-7 half a tile late", k_trunk_gen<256, 2, 1, 2>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
-        run("  VAR 4 barrier per two tiles, ring 5", k_trunk_gen<256, 2, 1, 4>, G::lds_bytes(5), 2, 256, 20, boards, 5, b, out, &ref);
-        run("  VAR 6 both", k_trunk_gen<256, 2, 1, 6>, G::lds_bytes(5), 2, 256, 20, boards, 5, b, out, &ref);
-        run("  VAR 1 weights via registers", k_trunk_gen<256, 2, 1, 1>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
-        run("  VAR 3 registers + late half", k_trunk_gen<256, 2, 1, 3>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
-        run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1, 0>, G::lds_bytes(4), 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_gen<256,2,1> production", k_trunk_gen<256, 2, 1>, G::LDS_BYTES, 2, 256, 20, boards, 5, b, ref, nullptr);
+        run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1>, G::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1> 16x16x32", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         stamps<256, 2>(b, 20, boards);
         run("  x16<256,2> no staging (timing)", k_trunk_x16<256, 2, 1, 3>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
@@ -157,25 +152,17 @@ int main(int argc, char **argv)
         Bufs b = make(64, 6, boards);
         printf("== 6 x 64, %d boards (4-board workgroups), then 512 boards (2-board workgroups)\n", boards);
         typedef Geo<64, 4> G4; typedef Geo<64, 2> G2;
-        run("k_trunk_gen<64,4,1> production", k_trunk_gen<64, 4, 1, 0>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, ref, nullptr);
-        run("  VAR 2 late half", k_trunk_gen<64, 4, 1, 2>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
-        run("  VAR 1 registers", k_trunk_gen<64, 4, 1, 1>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
-        run("  VAR 3 both", k_trunk_gen<64, 4, 1, 3>, G4::lds_bytes(4), 4, 64, 6, boards, reps, b, out, &ref);
+        run("k_trunk_gen<64,4,1> production", k_trunk_gen<64, 4, 1>, G4::LDS_BYTES, 4, 64, 6, boards, reps, b, ref, nullptr);
         run("k_trunk_x16<64,4,1> 16x16x32", k_trunk_x16<64, 4, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
         run("k_trunk_x16<64,4,1,1> alt issuer", k_trunk_x16<64, 4, 1, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
-        run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1, 0>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, ref, nullptr);
-        run("  VAR 2 late half", k_trunk_gen<64, 2, 1, 2>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
-        run("  VAR 1 registers", k_trunk_gen<64, 2, 1, 1>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
-        run("  VAR 3 both", k_trunk_gen<64, 2, 1, 3>, G2::lds_bytes(4), 2, 64, 6, 512, reps, b, out, &ref);
+        run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1>, G2::LDS_BYTES, 2, 64, 6, 512, reps, b, ref, nullptr);
         run("k_trunk_x16<64,2,1> 16x16x32 512", k_trunk_x16<64, 2, 1>, Geo16<64, 2>::LDS_BYTES, 2, 64, 6, 512, reps, b, out, &ref);
     }
     {
         Bufs b = make(128, 10, boards);
         printf("== 10 x 128 through the template, %d boards\n", boards);
         typedef Geo<128, 4> G;
-        run("k_trunk_gen<128,4,1>", k_trunk_gen<128, 4, 1, 0>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, ref, nullptr);
-        run("  VAR 2 late half", k_trunk_gen<128, 4, 1, 2>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, out, &ref);
-        run("  VAR 1 registers", k_trunk_gen<128, 4, 1, 1>, G::lds_bytes(4), 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_gen<128,4,1>", k_trunk_gen<128, 4, 1>, G::LDS_BYTES, 4, 128, 10, boards, reps, b, ref, nullptr);
     }
     return 0;
 }
