@@ -577,11 +577,13 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
     // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
     const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
-    // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count
+    // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count; 128 and 256
+    // filters with one barrier per two weight tiles over a five-slot ring (PAIR)
 #define CRL_X16(F_, NB_)                                                                        \
     do {                                                                                         \
-        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1> : crl_tower::k_trunk_x16<F_, NB_, 0>;   \
-        lds_bytes = crl_tower::Geo16<F_, NB_>::LDS_BYTES;                                        \
+        constexpr int pair = (F_ == 64) ? 0 : 1;                                                 \
+        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1, 0, pair> : crl_tower::k_trunk_x16<F_, NB_, 0, 0, pair>; \
+        lds_bytes = crl_tower::Geo16<F_, NB_>::lds_bytes(pair ? 5 : crl_tower::PIPE_RING);       \
         boards_per_wg = NB_;                                                                     \
     } while (0)
     if (filters == 256) {

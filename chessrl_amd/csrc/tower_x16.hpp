@@ -49,6 +49,7 @@ struct Geo16 {
     static constexpr int WRING_OFF = ((BIAS_OFF + 2 * F * 4 + 1023) / 1024) * 1024;
     static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int lds_bytes(int ring) { return WRING_OFF + ring * TILE_BYTES; }
     // LDS image of a weight tile: one plane per 32-channel sub-step, [SPT][F rows][64 bytes];
     // rows of 16 banks, chunk swizzle (-(row >> 2)) & 3: the 16 lanes of a ds_read_b128 group (8
     // rows at quarter q, 8 at q+1) cover all 64 banks, and the sub-step is an immediate offset.
@@ -64,10 +65,11 @@ struct Geo16 {
 // two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
 // goes straight back to its MFMAs.
 template <class G, int ALT>
-__device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, int t, int tid, int wave_u)
+__device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, int t, int tid, int wave_u,
+                                       int slot = -1)
 {
     const unsigned char *src = wts + (size_t)t * G::TILE_BYTES;
-    const int slot0 = G::WRING_OFF + (t & (PIPE_RING - 1)) * G::TILE_BYTES;
+    const int slot0 = G::WRING_OFF + (slot < 0 ? (t & (PIPE_RING - 1)) : slot) * G::TILE_BYTES;
     if constexpr (ALT == 1) {
         if ((wave_u >> 2) != (t & 1)) return;
         const int dst0 = slot0 + (wave_u & 3) * 1024;   // uniform
@@ -130,7 +132,10 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 //   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
-template <int F, int NB, int BITS = 0, int ALT = 0>
+// PAIR = 1 (128 and 256 filters): ONE barrier per TWO weight tiles over a ring of five slots.  The
+// sync sits at the start of the last sub-step of every odd tile t: tiles t+1, t+2 (moved at the
+// previous sync) are published, tiles t+3, t+4 go into the slots of the dead tiles t-2, t-1.
+template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -158,10 +163,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
+    static_assert(!PAIR || ((F == 128 || F == 256) && ALT == 0), "pair publishing: even tile counts per layer");
+    static_assert(G::lds_bytes(PAIR ? 5 : PIPE_RING) <= 160 * 1024, "LDS budget");
     stage_bias_x16<G, F>(bias, lds, 0, lane, wave_u);   // oldest transfer: landed when tile 0 has
-    stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u);
-    stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u);
-    stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u);
+    stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u, PAIR ? 0 : -1);
+    stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u, PAIR ? 1 : -1);
+    stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u, PAIR ? 2 : -1);
+    if constexpr (PAIR) stage_wtile_x16<G, ALT>(wts, lds, 3, tid, wave_u, 3);
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
         if constexpr (BITS) {
@@ -181,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) =
                 u32x4{0u, 0u, 0u, 0u};
     }
-    // tile 0 landed (tiles 1,2 may be in flight).  ALT: waves 0-3 moved tiles 0 and 2, waves 4-7 tile 1
+    // tile 0 landed (tiles 1,2 may be in flight).  ALT: waves 0-3 moved tiles 0 and 2, waves 4-7 tile 1.
+    // PAIR: tiles 0 AND 1 landed (1 is first read before the first sync), 2 and 3 in flight
     if constexpr (ALT == 1) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
     else wait_vmcnt<2 * G::GL>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -212,6 +221,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0, t_ba = 0, t_wr = 0;
     if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); t_mark = t_begin; }
     int t = 0;                                          // tile of the K-step being computed
+    int slot_tap = 0;                                   // PAIR: ring slot (t mod 5) of the tap's first tile
+    auto slot_add = [](int s, int k) { const int x = s + k; return x >= 5 ? x - 5 : x; };
     for (int conv = 0; conv < n_convs; conv++) {
         // the accumulators start from this layer's bias (LDS row conv & 1, staged one layer ahead):
         // the first MFMA of every chain takes it as its C operand, the epilogue adds nothing
@@ -247,17 +258,26 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
             };
-            // a tap's tiles sit in consecutive ring slots (a tap is 1, 2 or 4 tiles and starts on a
-            // multiple of that): slot and sub-step are immediates on top of the tap's first slot
-            static_assert((NS / G::SPT == 1 || NS / G::SPT == 2 || NS / G::SPT == 4) && PIPE_RING == 4, "ring");
-            const int wv_cur = w0 + (t_tap0 & (PIPE_RING - 1)) * G::TILE_BYTES;
-            const int wv_nxt = w0 + ((t_tap0 + NS / G::SPT) & (PIPE_RING - 1)) * G::TILE_BYTES;
+            // Ring of four: a tap's tiles sit in consecutive slots (a tap is 1, 2 or 4 tiles and
+            // starts on a multiple of that), so slot and sub-step are immediates on top of the tap's
+            // first slot.  Ring of five (PAIR): one base register per tile of the tap (slots wrap).
+            constexpr int TPT = NS / G::SPT;
+            static_assert((TPT == 1 || TPT == 2 || TPT == 4) && PIPE_RING == 4, "ring");
+            int wv[PAIR ? TPT : 1], wv_nxt;
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int k = 0; k < TPT; k++) wv[k] = w0 + slot_add(slot_tap, k) * G::TILE_BYTES;
+                wv_nxt = w0 + slot_add(slot_tap, TPT) * G::TILE_BYTES;
+            } else {
+                wv[0] = w0 + (t_tap0 & (PIPE_RING - 1)) * G::TILE_BYTES;
+                wv_nxt = w0 + ((t_tap0 + TPT) & (PIPE_RING - 1)) * G::TILE_BYTES;
+            }
             auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
                 constexpr int i = decltype(IC)::value;
                 static_for<0, CT>([&](auto CC) {
                     constexpr int ct = decltype(CC)::value;
-                    constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (i / G::SPT) * G::TILE_BYTES;
-                    dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv_cur);
+                    constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (PAIR ? 0 : (i / G::SPT) * G::TILE_BYTES);
+                    dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv[PAIR ? i / G::SPT : 0]);
                 });
             };
             if (first_tap) {
@@ -268,7 +288,23 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 constexpr int i = decltype(IC)::value;
                 constexpr int s = i % G::SPT;
                 constexpr int cur = i % 2, nxt = 1 - cur;
-                if constexpr (s == G::SPT - 1) {
+                if constexpr (PAIR) {
+                    if constexpr (s == G::SPT - 1 && ((i / G::SPT) & 1) == 1) {
+                        // start of the last sub-step of an odd tile t: tiles t+1, t+2 (moved at the
+                        // previous sync, the only transfers in flight) are published; tiles <= t-1
+                        // are dead and their slots take tiles t+3, t+4
+                        wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!bias_staged) {
+                            bias_staged = true;
+                            if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
+                        }
+                        const int slot_cur = slot_add(slot_tap, i / G::SPT);
+                        if (t + 3 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 3, tid, wave_u, slot_add(slot_cur, 3));
+                        if (t + 4 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 4, tid, wave_u, slot_add(slot_cur, 4));
+                    }
+                } else if constexpr (s == G::SPT - 1) {
                     // publish tile t+1 before the half that prefetches its first fragments;
                     // recycle tile t-1's slot
                     if constexpr (ALT == 1) {
@@ -354,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             vtap_rows(v + 1 < nv ? v + 1 : 0, ab[1]);
             if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, v == 0, v == nv - 1);
             else run_tap(std::integral_constant<int, 4>{}, v == 0, v == nv - 1);
+            if constexpr (PAIR) slot_tap = slot_add(slot_tap, 4 / G::SPT);
         }
 
         // ---- epilogue ------------------------------------------------------------------------------

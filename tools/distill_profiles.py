@@ -31,7 +31,7 @@ for tag, shape in shapes.items():
         if "k_trunk" not in k:
             continue
         short = k.split("::")[-1]
-        short = short[:short.rindex(",")] + ">"               # drop the ALT template argument (0)
+        short = ",".join(short.split(",")[:3]) + ">"          # <filters, boards per workgroup, bit planes>: drop ALT, PAIR
         passes.append({"kernel": short, "shape": shape, "fetch_size_kb": round(f[k][0], 1),
                        "write_size_kb": round(w[k][0], 1),
                        "source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc, tools/trunk_once.py, %d launches)" % f[k][1]})

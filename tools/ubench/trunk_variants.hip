@@ -126,6 +126,8 @@ int main(int argc, char **argv)
         run("k_trunk128_pipe<0,1> production", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, ref, nullptr);
         run("k_trunk128_pipe<0,1> again", k_trunk128_pipe<0, 1>, P2_LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> 16x16x32", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,4,1,0,1> pair sync", k_trunk_x16<128, 4, 1, 0, 1>, Geo16<128, 4>::lds_bytes(5), 4, 128, 10, boards, reps, b, out, &ref);
+        run("k_trunk_x16<128,4,1> again", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1,1> alt issuer", k_trunk_x16<128, 4, 1, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> again", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         stamps<128, 4>(b, 10, boards);
@@ -146,6 +148,8 @@ int main(int argc, char **argv)
         run("  x16<256,2> no staging (timing)", k_trunk_x16<256, 2, 1, 3>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("  x16<256,2> no barrier (timing)", k_trunk_x16<256, 2, 1, 4>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("  x16<256,2> neither (timing)", k_trunk_x16<256, 2, 1, 5>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_x16<256,2,1,0,1> pair sync", k_trunk_x16<256, 2, 1, 0, 1>, Geo16<256, 2>::lds_bytes(5), 2, 256, 20, boards, 5, b, out, &ref);
+        run("k_trunk_x16<256,2,1> again", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1,1> alt issuer", k_trunk_x16<256, 2, 1, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
     }
     {
