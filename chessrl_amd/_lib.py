@@ -51,7 +51,7 @@ SYMBOLS = [
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
-    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch",
+    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch", "crl_heads_forward",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -153,6 +153,7 @@ def lib():
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_trunk_set_small_batch.argtypes = [i32]
+    L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:

@@ -8,6 +8,7 @@
 #include "tower_pipe.hpp"
 #include "tower_gen.hpp"
 #include "tower_x16.hpp"
+#include "heads.hpp"
 #include "train_ops.hpp"
 
 #include <atomic>
@@ -670,6 +671,28 @@ int crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_b
 {
     return trunk_forward(hip_stream, filters, dev_bitplanes_u64, true, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
                          n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
+}
+
+int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                      const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                      const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                      const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32)
+{
+    if (!dev_head_act_f32 || n_boards < 1 || !dev_policy_wp_f16 || !dev_policy_bias_f32 || !dev_policy_out_f32 ||
+        (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
+        return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward: bad argument");
+    const unsigned blocks = (unsigned)((n_boards + 15) / 16);
+    hipLaunchKernelGGL(crl_heads::k_policy_head, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
+                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
+                       (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
+    if (dev_value_out_f32)
+        hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
+                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,
+                           (const float *)dev_value_b1_f32, (const float *)dev_value_w2b2_f32,
+                           (float *)dev_value_out_f32);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
 }
 
 static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, int channels, bool forward)

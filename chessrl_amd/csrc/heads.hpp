@@ -1,0 +1,177 @@
+// heads.hpp -- the dense layers behind the tower's two head convolutions, on MFMA.
+//
+// Reference (paths relative to /root/reference/src/chessrl/): model.py:44-48 -- policy head
+// Flatten -> Dense(1968, softmax); model.py:56-61 -- value head Flatten -> Dense(256, relu) ->
+// Dense(1, tanh).  Inputs are the 192 head activations per board that the trunk kernel leaves
+// (csrc/tower_x16.hpp: [0,128) policy, Keras Flatten order; [128,192) value).
+//
+// Round 1 ran these as three rocBLAS fp32 GEMMs + softmax + elementwise kernels (8 launches, 45-65 us
+// per forward at 4096 boards, 20-35 us at 512: 4 % of a C3 step, 25 % of a C2 step).  Here: ONE
+// launch per head.  fp32 accuracy comes from fp16 MFMAs on split operands: x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi), and  W.h ~= Whi.hhi + Wlo.hhi + Whi.hlo  (the dropped lo.lo
+// term is 2^-22 relative), accumulated in fp32 -- three v_mfma_f32_16x16x32_f16 per 16x16x32 block,
+// 5x cheaper than v_mfma_f32_16x16x4_f32 (fp32 MFMA runs at the vector rate on gfx950).
+//
+// Orientation: D[output unit][board] = W^T . h^T, so a lane holds 4 consecutive output units of ONE
+// board (lane = 16 q + r: board r of the 16-board block, units 4q..4q+3 of the 16-unit tile).  The
+// weight operand is packed on the host in fragment order [tile][k-step][hi|lo][lane][8 halves] (one
+// coalesced 1-KiB load per fragment, served by L2); the activation operand is split in-kernel.
+#pragma once
+#include "tower_common.hpp"
+
+namespace crl_heads {
+
+using crl_tower::half8;
+typedef float f32x4h __attribute__((ext_vector_type(4)));
+
+constexpr int N_LABELS = 1968;
+constexpr int N_LABELS_PAD = 2048;       // 8 waves x 16 tiles x 16 labels
+constexpr int ACT = 192;                 // head activations per board
+
+// activation fragments of k-step s for the 16-board block: lane (r, q) holds h[board0 + r][k0 + 32 s + 8 q ..+8]
+__device__ __forceinline__ void split_act(const float *row, bool valid, int k, half8 &hi, half8 &lo)
+{
+    float x[8];
+    if (valid) {
+        const f32x4h a = *reinterpret_cast<const f32x4h *>(row + k);
+        const f32x4h b = *reinterpret_cast<const f32x4h *>(row + k + 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { x[e] = a[e]; x[4 + e] = b[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+// ---- policy head: softmax(h[128] . W[128][1968] + b) -> policy[n][1968] ---------------------------
+// One 512-thread workgroup per 16 boards; wave w owns labels [256 w, 256 w + 256) (16 tiles).
+// Softmax statistics meet in LDS in a fixed order (no atomics: reproducible).
+__global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict__ act, int n_boards,
+                                                        const unsigned char *__restrict__ wp,   // packed fp16
+                                                        const float *__restrict__ bias,          // [2048], pad = -1e30
+                                                        float *__restrict__ policy)
+{
+    __shared__ float s_max[8][16], s_sum[8][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int board = blockIdx.x * 16 + r;
+    const bool valid = board < n_boards;
+    const float *row = act + (size_t)board * ACT;
+
+    half8 hhi[4], hlo[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
+
+    // weight fragments of this wave: tiles 16 wave .. 16 wave + 15, each 4 k-steps x (hi, lo) x 1 KiB
+    const half8 *wf = reinterpret_cast<const half8 *>(wp) + (size_t)(wave * 16) * (4 * 2 * 64) + lane;
+    f32x4h acc[16];
+    half8 a[2][8];                                       // [buffer][2 s + hl]: one tile ahead
+#pragma unroll
+    for (int f = 0; f < 8; f++) a[0][f] = wf[f * 64];
+#pragma unroll
+    for (int jt = 0; jt < 16; jt++) {
+        const int cur = jt & 1;
+        if (jt + 1 < 16) {
+#pragma unroll
+            for (int f = 0; f < 8; f++) a[cur ^ 1][f] = wf[((jt + 1) * 8 + f) * 64];
+        }
+        f32x4h d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s + 1], hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hlo[s], d, 0, 0, 0);
+        }
+        const f32x4h bv = *reinterpret_cast<const f32x4h *>(bias + wave * 256 + jt * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] += bv[j];
+        acc[jt] = d;
+    }
+    // ---- softmax over the 2048 (padded) labels of board r
+    float m = acc[0][0];
+#pragma unroll
+    for (int jt = 0; jt < 16; jt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) m = fmaxf(m, acc[jt][j]);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (q == 0) s_max[wave][r] = m;
+    __syncthreads();
+    float mx = s_max[0][r];
+#pragma unroll
+    for (int w = 1; w < 8; w++) mx = fmaxf(mx, s_max[w][r]);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 16; jt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float e = __expf(acc[jt][j] - mx);
+            acc[jt][j] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (q == 0) s_sum[wave][r] = sum;
+    __syncthreads();
+    float tot = s_sum[0][r];
+#pragma unroll
+    for (int w = 1; w < 8; w++) tot += s_sum[w][r];
+    const float inv = 1.0f / tot;
+    if (valid) {
+        float *out = policy + (size_t)board * N_LABELS + wave * 256 + 4 * q;
+#pragma unroll
+        for (int jt = 0; jt < 16; jt++) {
+            if (wave * 256 + jt * 16 < N_LABELS) {       // 1968 = 123 tiles: whole tiles only
+                f32x4h p;
+#pragma unroll
+                for (int j = 0; j < 4; j++) p[j] = acc[jt][j] * inv;
+                *reinterpret_cast<f32x4h *>(out + jt * 16) = p;
+            }
+        }
+    }
+}
+
+// ---- value head: tanh(relu(h[64] . W1[64][256] + b1) . W2[256] + b2) -> value[n] -------------------
+// One wavefront per 16 boards.
+__global__ __launch_bounds__(64) void k_value_head(const float *__restrict__ act, int n_boards,
+                                                   const unsigned char *__restrict__ w1p,    // packed fp16
+                                                   const float *__restrict__ b1,
+                                                   const float *__restrict__ w2,             // [257]: w2, then b2
+                                                   float *__restrict__ value)
+{
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int board = blockIdx.x * 16 + r;
+    const bool valid = board < n_boards;
+    const float *row = act + (size_t)board * ACT + 128;
+    half8 hhi[2], hlo[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
+    const half8 *wf = reinterpret_cast<const half8 *>(w1p) + lane;
+    float z = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 16; jt++) {
+        f32x4h d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const half8 ahi = wf[((jt * 2 + s) * 2 + 0) * 64], alo = wf[((jt * 2 + s) * 2 + 1) * 64];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hlo[s], d, 0, 0, 0);
+        }
+        const f32x4h bv = *reinterpret_cast<const f32x4h *>(b1 + jt * 16 + 4 * q);
+        const f32x4h wv = *reinterpret_cast<const f32x4h *>(w2 + jt * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; j++) z += fmaxf(d[j] + bv[j], 0.f) * wv[j];
+    }
+    z += __shfl_xor(z, 16);
+    z += __shfl_xor(z, 32);
+    if (valid && q == 0) value[board] = tanhf(z + w2[256]);    // b2 from memory: weights may change under a captured graph
+}
+
+}  // namespace crl_heads

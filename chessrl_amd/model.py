@@ -225,14 +225,39 @@ class ChessModel(object):
         kv, bv = _fold(w, "value.conv", "value.bn")            # [1][F][1][1]
         new = (torch.cat(tiles).to(torch.float16), torch.stack(biases).float(),
                torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).float(), torch.cat([bp, bv]).float())
+        new = new + self._pack_dense(w)
+        names = ("_wtiles", "_wbias", "_head_w", "_head_b", "_pol_wp", "_pol_bias", "_val_w1p", "_val_b1", "_val_w2")
         if getattr(self, "_wtiles", None) is None:
-            self._wtiles, self._wbias, self._head_w, self._head_b = (
-                t.to(self.device).contiguous() for t in new)
+            for name, t in zip(names, new):
+                setattr(self, name, t.to(self.device).contiguous())
             self._pad_in = None
             self._pad_bits = None
         else:                                                  # in place: captured graphs stay valid
-            for dst, src in zip((self._wtiles, self._wbias, self._head_w, self._head_b), new):
-                dst.copy_(src)
+            for name, src in zip(names, new):
+                getattr(self, name).copy_(src)
+
+    @staticmethod
+    def _pack_split(x, tiles, ksteps):
+        """fp32 [tiles*16 units][ksteps*32 inputs] -> fp16 (hi, lo) MFMA fragments in the order
+        csrc/heads.hpp reads them: [tile][k-step][hi|lo][lane = 16 q + r][8], the lane holding
+        x[16 tile + r][32 s + 8 q + e]."""
+        hi = x.half()
+        lo = (x - hi.float()).half()
+        frag = torch.stack([hi, lo])                                         # [2][units][inputs]
+        frag = frag.reshape(2, tiles, 16, ksteps, 4, 8)                      # [hl][t][r][s][q][e]
+        return frag.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)       # [t][s][hl][q][r][e]
+
+    def _pack_dense(self, w):
+        """Dense layers of the two heads (model.py:44-48, 56-61) for crl_heads_forward."""
+        wp = torch.zeros((2048, 128))
+        wp[:N_POLICY] = torch.from_numpy(np.asarray(w["policy.dense.kernel"], np.float32)).t()
+        pb = torch.full((2048,), -1e30)
+        pb[:N_POLICY] = torch.from_numpy(np.asarray(w["policy.dense.bias"], np.float32))
+        w1 = torch.from_numpy(np.asarray(w["value.dense1.kernel"], np.float32)).t().contiguous()    # [256][64]
+        return (self._pack_split(wp, 128, 4), pb.float(), self._pack_split(w1, 16, 2),
+                torch.from_numpy(np.asarray(w["value.dense1.bias"], np.float32)).clone(),
+                torch.cat([torch.from_numpy(np.asarray(w["value.dense2.kernel"], np.float32)).reshape(-1),
+                           torch.from_numpy(np.asarray(w["value.dense2.bias"], np.float32)).reshape(-1)]))    # w2, b2
 
     def _run_fused(self, planes, want_trunk=False):
         """One launch of the fused trunk kernel.  ``planes``: fp16 NHWC [B,8,8,128], or int64
@@ -271,16 +296,24 @@ class ChessModel(object):
         return (trunk[:b] if want_trunk else None), heads[:b]
 
     def _forward_fused(self, planes, pol_out=None, val_out=None):
-        """Fused trunk + head convs in the HIP kernel; the dense layers (model.py:44-48,56-61)
-        are three small fp32 GEMMs, written straight into the caller's buffers when given."""
+        """Fused trunk + head convs in one HIP kernel, then the dense layers (model.py:44-48,56-61)
+        in one launch per head (csrc/heads.hpp), written straight into the caller's buffers."""
+        import ctypes
+        from . import _lib
         _, hp = self._run_fused(planes)
-        n = self.net
-        p = torch.softmax(n.policy_fc(hp[:, :128]), dim=-1, out=pol_out)
-        if pol_out is not None and val_out is None:
-            return p, None                       # S1 evaluations only choose the reply: no value head
-        v = F.relu(n.value_fc1(hp[:, 128:]))
-        z = n.value_fc2(v)[:, 0]
-        v = torch.tanh(z, out=val_out) if val_out is not None else torch.tanh(z)
+        b = hp.shape[0]
+        want_value = not (pol_out is not None and val_out is None)   # S1 evaluations only choose the reply
+        p = pol_out if pol_out is not None else torch.empty((b, N_POLICY), dtype=torch.float32, device=self.device)
+        v = None
+        if want_value:
+            v = val_out if val_out is not None else torch.empty((b,), dtype=torch.float32, device=self.device)
+        vp = ctypes.c_void_p
+        rc = _lib.lib().crl_heads_forward(
+            vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), b,
+            vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
+            vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(p.data_ptr()), vp(v.data_ptr() if v is not None else None))
+        if rc != 0:
+            raise _lib.HipLibraryError("crl_heads_forward failed (%d)" % rc)
         return p, v
 
     @torch.no_grad()

@@ -197,6 +197,22 @@ int  crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_
                                  int n_boards, int n_blocks, const void *dev_head_w_f32,
                                  const void *dev_head_b_f32, void *dev_head_out_f32);
 
+/* The dense layers behind the head convolutions (model.py:44-48: Dense(1968, softmax); model.py:56-61:
+ * Dense(256, relu) -> Dense(1, tanh)) on the [n_boards][192] head activations crl_trunk_forward
+ * leaves: one launch per head, fp32-accurate through fp16 MFMAs on (hi, lo)-split operands.
+ * dev_policy_wp_f16: the policy kernel W[128 in][1968 out] packed in fragment order
+ * [label tile 128][k-step 4][hi|lo][lane 64][8 halves], lane 16 q + r holding
+ * W[32 s + 8 q + e][16 tile + r] (labels >= 1968 zero): 1 MiB; dev_policy_bias_f32: [2048], entries
+ * >= 1968 set to -1e30.  dev_value_w1p_f16: W1[64 in][256 out] packed the same way
+ * [tile 16][k-step 2][hi|lo][lane][8]: 64 KiB; b1 [256]; dev_value_w2b2_f32 [257] = w2 then b2 (in
+ * memory, not by value: weights may be rewritten in place under a captured hipGraph).
+ * dev_policy_out_f32: [n_boards][1968] probabilities; dev_value_out_f32: [n_boards] or NULL (the
+ * value head is skipped: evaluations of S1 only choose the reply).  Stateless. */
+int  crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                       const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                       const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                       const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32);
+
 /* Batches of at most 512 boards (256 at 256 filters) give at most half of the 256 CUs a
  * workgroup; they run the same kernels with half the boards per workgroup and twice the
  * workgroups (identical trunk bits).  enabled = 0 turns that off process-wide (default 1). */
