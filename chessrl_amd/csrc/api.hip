@@ -682,9 +682,16 @@ int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boar
         (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
         return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward: bad argument");
     const unsigned blocks = (unsigned)((n_boards + 15) / 16);
-    hipLaunchKernelGGL(crl_heads::k_policy_head, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
-                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
-                       (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
+    // every policy workgroup streams the whole packed kernel from L2: 32 boards per workgroup once
+    // that still leaves every CU a workgroup
+    if (n_boards >= 1 << 30)                 // 32-board workgroups: measured no faster (the launch is latency-, not L2-bound)
+        hipLaunchKernelGGL(crl_heads::k_policy_head<2>, dim3((blocks + 1) / 2), dim3(512), 0, (hipStream_t)hip_stream,
+                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
+                           (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
+    else
+        hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
+                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
+                           (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
     if (dev_value_out_f32)
         hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
                            (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,

@@ -50,88 +50,123 @@ __device__ __forceinline__ void split_act(const float *row, bool valid, int k, h
 }
 
 // ---- policy head: softmax(h[128] . W[128][1968] + b) -> policy[n][1968] ---------------------------
-// One 512-thread workgroup per 16 boards; wave w owns labels [256 w, 256 w + 256) (16 tiles).
-// Softmax statistics meet in LDS in a fixed order (no atomics: reproducible).
+// One 512-thread workgroup per 16 NBLK boards; wave w owns labels [256 w, 256 w + 256) (16 tiles) of
+// all its boards.  Every workgroup streams the whole packed kernel (1 MiB) from L2, which is what
+// bounds the launch (256 workgroups x 1 MiB at ~10 TB/s): NBLK = 2 halves that traffic for large
+// batches; NBLK = 1 keeps twice the workgroups for small ones.  Softmax statistics meet in LDS in a
+// fixed order (no atomics: reproducible).
+template <int NBLK>
 __global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict__ act, int n_boards,
                                                         const unsigned char *__restrict__ wp,   // packed fp16
                                                         const float *__restrict__ bias,          // [2048], pad = -1e30
                                                         float *__restrict__ policy)
 {
-    __shared__ float s_max[8][16], s_sum[8][16];
+    __shared__ float s_max[NBLK][8][16], s_sum[NBLK][8][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int board = blockIdx.x * 16 + r;
-    const bool valid = board < n_boards;
-    const float *row = act + (size_t)board * ACT;
-
-    half8 hhi[4], hlo[4];
+    int board[NBLK];
+    bool valid[NBLK];
+    half8 hhi[NBLK][4], hlo[NBLK][4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
-
+    for (int nb = 0; nb < NBLK; nb++) {
+        board[nb] = (blockIdx.x * NBLK + nb) * 16 + r;
+        valid[nb] = board[nb] < n_boards;
+        const float *row = act + (size_t)board[nb] * ACT;
+#pragma unroll
+        for (int s = 0; s < 4; s++) split_act(row, valid[nb], 32 * s + 8 * q, hhi[nb][s], hlo[nb][s]);
+    }
     // weight fragments of this wave: tiles 16 wave .. 16 wave + 15, each 4 k-steps x (hi, lo) x 1 KiB
     const half8 *wf = reinterpret_cast<const half8 *>(wp) + (size_t)(wave * 16) * (4 * 2 * 64) + lane;
-    f32x4h acc[16];
-    half8 a[2][8];                                       // [buffer][2 s + hl]: one tile ahead
+    f32x4h acc[NBLK][16];
+    // the wave is bound by the latency of its weight loads (8 KiB per tile from L2), not by their
+    // bandwidth: a ring of AHEAD + 1 tile buffers keeps AHEAD tiles in flight
+    constexpr int AHEAD = NBLK == 1 ? 3 : 1;
+    half8 a[AHEAD + 1][8];                               // [buffer][2 s + hl]
+    f32x4h bvr[AHEAD + 1];                               // the tile's bias travels with its fragments:
+    const float *bsrc = bias + wave * 256 + 4 * q;       // a load issued at its use would need vmcnt(0)
 #pragma unroll
-    for (int f = 0; f < 8; f++) a[0][f] = wf[f * 64];
+    for (int p = 0; p < AHEAD; p++) {
+#pragma unroll
+        for (int f = 0; f < 8; f++) a[p][f] = wf[(p * 8 + f) * 64];
+        bvr[p] = *reinterpret_cast<const f32x4h *>(bsrc + p * 16);
+    }
 #pragma unroll
     for (int jt = 0; jt < 16; jt++) {
-        const int cur = jt & 1;
-        if (jt + 1 < 16) {
+        const int cur = jt % (AHEAD + 1);
+        if (jt + AHEAD < 16) {
 #pragma unroll
-            for (int f = 0; f < 8; f++) a[cur ^ 1][f] = wf[((jt + 1) * 8 + f) * 64];
+            for (int f = 0; f < 8; f++) a[(jt + AHEAD) % (AHEAD + 1)][f] = wf[((jt + AHEAD) * 8 + f) * 64];
+            bvr[(jt + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x4h *>(bsrc + (jt + AHEAD) * 16);
         }
-        f32x4h d = {0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads AHEAD tiles early (hipcc sinks them to their use)
+        const f32x4h bv = bvr[cur];
+        f32x4h d[NBLK];
+#pragma unroll
+        for (int nb = 0; nb < NBLK; nb++) d[nb] = f32x4h{bv[0], bv[1], bv[2], bv[3]};     // bias = C operand
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hhi[s], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s + 1], hhi[s], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hlo[s], d, 0, 0, 0);
-        }
-        const f32x4h bv = *reinterpret_cast<const f32x4h *>(bias + wave * 256 + jt * 16 + 4 * q);
 #pragma unroll
-        for (int j = 0; j < 4; j++) d[j] += bv[j];
-        acc[jt] = d;
+            for (int nb = 0; nb < NBLK; nb++)
+                d[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hhi[nb][s], d[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; nb++)
+                d[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s + 1], hhi[nb][s], d[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; nb++)
+                d[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][2 * s], hlo[nb][s], d[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBLK; nb++) acc[nb][jt] = d[nb];
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- softmax over the 2048 (padded) labels of board r
-    float m = acc[0][0];
+    // ---- softmax over the 2048 (padded) labels of each board
 #pragma unroll
-    for (int jt = 0; jt < 16; jt++)
+    for (int nb = 0; nb < NBLK; nb++) {
+        float m = acc[nb][0][0];
 #pragma unroll
-        for (int j = 0; j < 4; j++) m = fmaxf(m, acc[jt][j]);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    if (q == 0) s_max[wave][r] = m;
+        for (int jt = 0; jt < 16; jt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) m = fmaxf(m, acc[nb][jt][j]);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (q == 0) s_max[nb][wave][r] = m;
+    }
     __syncthreads();
-    float mx = s_max[0][r];
 #pragma unroll
-    for (int w = 1; w < 8; w++) mx = fmaxf(mx, s_max[w][r]);
-    float sum = 0.f;
+    for (int nb = 0; nb < NBLK; nb++) {
+        float mx = s_max[nb][0][r];
 #pragma unroll
-    for (int jt = 0; jt < 16; jt++)
+        for (int w = 1; w < 8; w++) mx = fmaxf(mx, s_max[nb][w][r]);
+        float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float e = __expf(acc[jt][j] - mx);
-            acc[jt][j] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (q == 0) s_sum[wave][r] = sum;
+        for (int jt = 0; jt < 16; jt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float e = __expf(acc[nb][jt][j] - mx);
+                acc[nb][jt][j] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (q == 0) s_sum[nb][wave][r] = sum;
+    }
     __syncthreads();
-    float tot = s_sum[0][r];
 #pragma unroll
-    for (int w = 1; w < 8; w++) tot += s_sum[w][r];
-    const float inv = 1.0f / tot;
-    if (valid) {
-        float *out = policy + (size_t)board * N_LABELS + wave * 256 + 4 * q;
+    for (int nb = 0; nb < NBLK; nb++) {
+        float tot = s_sum[nb][0][r];
 #pragma unroll
-        for (int jt = 0; jt < 16; jt++) {
-            if (wave * 256 + jt * 16 < N_LABELS) {       // 1968 = 123 tiles: whole tiles only
-                f32x4h p;
+        for (int w = 1; w < 8; w++) tot += s_sum[nb][w][r];
+        const float inv = 1.0f / tot;
+        if (valid[nb]) {
+            float *out = policy + (size_t)board[nb] * N_LABELS + wave * 256 + 4 * q;
 #pragma unroll
-                for (int j = 0; j < 4; j++) p[j] = acc[jt][j] * inv;
-                *reinterpret_cast<f32x4h *>(out + jt * 16) = p;
+            for (int jt = 0; jt < 16; jt++) {
+                if (wave * 256 + jt * 16 < N_LABELS) {   // 1968 = 123 tiles: whole tiles only
+                    f32x4h p;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) p[j] = acc[nb][jt][j] * inv;
+                    *reinterpret_cast<f32x4h *>(out + jt * 16) = p;
+                }
             }
         }
     }

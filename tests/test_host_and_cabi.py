@@ -224,3 +224,21 @@ def test_bench_gpus_2_starts_two_ranks_and_checks_the_world(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
     assert r.returncode != 0 and "--gpus 2" in r.stderr and "{" not in r.stdout
+
+
+def test_dense_head_weight_packing_is_the_fragment_order_the_kernel_reads():
+    """ChessModel._pack_split -> [tile][k-step][hi|lo][lane = 16 q + r][8 halves] with the lane
+    holding x[16 tile + r][32 s + 8 q + e] (csrc/heads.hpp), and hi + lo == x to 2^-22."""
+    import torch
+    from chessrl_amd.model import ChessModel
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((48, 64), generator=g) * 0.3                  # 3 tiles of 16 units, 2 k-steps
+    packed = ChessModel._pack_split(x, 3, 2).reshape(3, 2, 2, 64, 8).float()
+    for t in range(3):
+        for s in range(2):
+            for lane in (0, 5, 16, 37, 63):
+                r, q = lane & 15, lane >> 4
+                want = x[16 * t + r, 32 * s + 8 * q: 32 * s + 8 * q + 8]
+                hi, lo = packed[t, s, 0, lane], packed[t, s, 1, lane]
+                assert torch.equal(hi, want.half().float())
+                assert (hi + lo - want).abs().max() <= want.abs().max() * 2.0 ** -21
