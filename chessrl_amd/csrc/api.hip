@@ -174,13 +174,12 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     bool ok = true;
 #define A(ptr, count) ok = ok && (dalloc(ctx, &(ptr), (count)) == hipSuccess)
 #define AN(ptr, count) ok = ok && (dalloc(ctx, &(ptr), (count), false) == hipSuccess)
-    A(d.cur, G); A(d.ply, G); A(d.hist, G * HIST_RING); A(d.hist_hash, G * HIST_RING);
-    A(d.rec_moves, G * (size_t)d.MAXPLY); A(d.game_result, G);
-    A(d.n_nodes, G); A(d.edge_top, G); A(d.root_visits, G); A(d.root_dead, G);
-    AN(d.meta, GN); AN(d.nb1, GN); AN(d.nb2, GN); AN(d.nh1, GN); AN(d.nh2, GN); AN(d.n_reply, GN);
+    A(d.game, G); A(d.cur, G); A(d.hist, G * HIST_RING); A(d.hist_hash, G * HIST_RING);
+    A(d.rec_moves, G * (size_t)d.MAXPLY);
+    AN(d.node, GN);
     AN(d.edge, GE);
-    A(d.path_len, G); AN(d.path_edge, GN); AN(d.path_node, GN); A(d.leaf_node, G); A(d.leaf_kind, G);
-    A(d.s1_moves, G * MAX_MOVES); A(d.s1_n, G);
+    AN(d.path_edge, GN); AN(d.path_node, GN);
+    A(d.s1_moves, G * MAX_MOVES);
     A(d.counters, G * CNT_N); A(d.err, 1);
     A(ctx->t_moves, G * MAX_MOVES); A(ctx->t_moves2, G * MAX_MOVES); A(ctx->t_i32a, G * MAX_MOVES);
     A(ctx->t_i32b, G); A(ctx->t_i32c, G); A(ctx->t_f64, G * MAX_MOVES); A(ctx->t_f32, G * MAX_MOVES);
@@ -191,7 +190,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
 #undef AN
     if (!ok) {
         std::string msg = "crl_create: hipMalloc failed (pools need about " +
-                          std::to_string((GE * sizeof(Edge) + GN * 170) >> 20) + " MiB)";
+                          std::to_string((GE * sizeof(Edge) + GN * (sizeof(NodeRow) + 8)) >> 20) + " MiB)";
         for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, CRL_ERR_HIP, msg);
@@ -382,7 +381,8 @@ int crl_results(crl_ctx *ctx, int8_t *result)
 {
     if (!ctx || !result) return fail(ctx, CRL_ERR_ARG, "crl_results: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result + ctx->d.g0, ctx->W, hipMemcpyDeviceToHost, ctx->stream));
+    LAUNCH(ctx, k_game_scalars, ctx->d, ctx->t_i32b, (int8_t *)ctx->t_u8);
+    HIP_TRY(ctx, hipMemcpyAsync(result, ctx->t_u8, ctx->W, hipMemcpyDeviceToHost, ctx->stream));
     return check_dev_error(ctx);
 }
 
@@ -393,9 +393,10 @@ int crl_records(crl_ctx *ctx, uint16_t *moves, int32_t *plies, int8_t *result)
     const size_t G = ctx->W;
     if (moves)
         HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->d.rec_moves + (size_t)ctx->d.g0 * ctx->d.MAXPLY, G * ctx->d.MAXPLY * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->d.ply + ctx->d.g0, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    LAUNCH(ctx, k_game_scalars, ctx->d, ctx->t_i32b, (int8_t *)ctx->t_u8);
+    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->t_i32b, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (result)
-        HIP_TRY(ctx, hipMemcpyAsync(result, ctx->d.game_result + ctx->d.g0, G, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(result, ctx->t_u8, G, hipMemcpyDeviceToHost, ctx->stream));
     return check_dev_error(ctx);
 }
 

@@ -47,8 +47,8 @@ __device__ inline PastRef past_ref(const Dev &d, int g, int tp, int ply0, int pl
     if (tp >= 1) {
         int node = d.path_node[(size_t)g * d.N + ((tp + 1) >> 1)];
         size_t ni = (size_t)g * d.N + node;
-        r.b = (tp & 1) ? d.nb1 + ni : d.nb2 + ni;
-        r.h = (tp & 1) ? d.nh1 + ni : d.nh2 + ni;
+        r.b = (tp & 1) ? &d.node[ni].s1 : &d.node[ni].s2;
+        r.h = (tp & 1) ? &d.node[ni].h1 : &d.node[ni].h2;
         r.valid = true;
     } else {
         int p = ply0 + tp;
@@ -152,8 +152,10 @@ __device__ inline void encode_position(const Dev &d, int g, const Board &b, int 
     u64 p8[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) p8[k] = s.pl[cg * 8 + k];
+    // (not unrolled: sixteen loop-invariant 64-bit store addresses, hoisted to the top of
+    // k_select_expand, were what spilled 28 VGPRs there)
     uint4 *out = (uint4 *)planes_out + (size_t)row * (64 * PLANES * 2 / 16);
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < 16; t++) {
         const int sq = (t * 4 + (lane >> 4)) ^ 56;
         u32 w[4];
@@ -222,7 +224,7 @@ __device__ inline int argmax_policy(const Dev &d, int row, const u16 *mv, int n,
 // push a legal move onto the game (python-chess Board.push + result bookkeeping)
 __device__ inline void game_push(const Dev &d, int g, const Board &b, u32 mv, int lane, WaveLds &s)
 {
-    const int p = d.ply[g];
+    const int p = d.game[g].ply;
     Board nb = apply_move(b, mv);
     PosEval e = eval_position(d, g, nb, 0, p + 1, p, lane, s);
     if (lane == 0) {
@@ -233,9 +235,9 @@ __device__ inline void game_push(const Dev &d, int g, const Board &b, u32 mv, in
             d.hist_hash[hi] = e.hash;
             d.rec_moves[(size_t)g * d.MAXPLY + p] = (u16)mv;
             d.cur[g] = e.b;
-            d.ply[g] = p + 1;
-            d.game_result[g] = (int8_t)e.result;
-            d.root_dead[g] = 1;
+            d.game[g].ply = p + 1;
+            d.game[g].game_result = (int8_t)e.result;
+            d.game[g].root_dead = 1;
         }
     }
 }
@@ -260,15 +262,15 @@ __global__ __launch_bounds__(64) void k_set_positions(Dev d, const Board *in, co
         b.state &= 0xFFFFFu;
         b.pad = 0;
     }
-    if (lane == 0) d.ply[g] = 0;
+    if (lane == 0) d.game[g].ply = 0;
     PosEval e = eval_position(d, g, b, 0, 0, -1, lane, s);
     if (lane == 0) {
         d.cur[g] = e.b;
         d.hist[(size_t)g * HIST_RING] = e.b;
         d.hist_hash[(size_t)g * HIST_RING] = e.hash;
-        d.game_result[g] = (int8_t)e.result;
-        d.root_dead[g] = 1;
-        d.leaf_kind[g] = LEAF_NONE;
+        d.game[g].game_result = (int8_t)e.result;
+        d.game[g].root_dead = 1;
+        d.game[g].leaf_kind = LEAF_NONE;
     }
 }
 
@@ -327,12 +329,19 @@ __global__ __launch_bounds__(64) void k_push_seq(Dev d, const u16 *seq, const in
     if (lane == 0) pushed[r] = i;
 }
 
+// len(Game) and Game.get_result() of every slot of the window, as contiguous arrays for the host
+__global__ __launch_bounds__(64) void k_game_scalars(Dev d, int32_t *plies, int8_t *results)
+{
+    const int r = blockIdx.x, g = r + d.g0;
+    if (threadIdx.x == 0) { plies[r] = d.game[g].ply; results[r] = d.game[g].game_result; }
+}
+
 __global__ __launch_bounds__(64) void k_encode_cur(Dev d, void *planes)
 {
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     Board b = d.cur[g];
-    const int p = d.ply[g];
+    const int p = d.game[g].ply;
     encode_position(d, g, b, 0, p, p, lane, s, planes, r);
 }
 
@@ -351,14 +360,14 @@ __global__ __launch_bounds__(64) void k_greedy(Dev d, const float *pol, const ui
     const u32 mv = s.mv[bi];
     __syncthreads();
     if (lane == 0) moves_out[r] = (u16)mv;
-    if (push && d.game_result[g] == RESULT_NONE) game_push(d, g, b, mv, lane, s);
+    if (push && d.game[g].game_result == RESULT_NONE) game_push(d, g, b, mv, lane, s);
 }
 
 // Game.get_copy (game.py:79-80): deep copy incl. the move stack, slot src -> slot dst
 __global__ __launch_bounds__(64) void k_copy_game(Dev d, int dst, int src)
 {
     const int lane = threadIdx.x;
-    const int p = d.ply[src];
+    const int p = d.game[src].ply;
     for (int i = lane; i < HIST_RING; i += 64) {
         d.hist[(size_t)dst * HIST_RING + i] = d.hist[(size_t)src * HIST_RING + i];
         d.hist_hash[(size_t)dst * HIST_RING + i] = d.hist_hash[(size_t)src * HIST_RING + i];
@@ -367,10 +376,10 @@ __global__ __launch_bounds__(64) void k_copy_game(Dev d, int dst, int src)
         d.rec_moves[(size_t)dst * d.MAXPLY + i] = d.rec_moves[(size_t)src * d.MAXPLY + i];
     if (lane == 0) {
         d.cur[dst] = d.cur[src];
-        d.ply[dst] = p;
-        d.game_result[dst] = d.game_result[src];
-        d.root_dead[dst] = 1;
-        d.leaf_kind[dst] = LEAF_NONE;
+        d.game[dst].ply = p;
+        d.game[dst].game_result = d.game[src].game_result;
+        d.game[dst].root_dead = 1;
+        d.game[dst].leaf_kind = LEAF_NONE;
     }
 }
 
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(64) void k_copy_game(Dev d, int dst, int src)
 __global__ __launch_bounds__(64) void k_copy_game_across(Dev d, int dst, Dev sd, int src)
 {
     const int lane = threadIdx.x;
-    const int p = sd.ply[src];
+    const int p = sd.game[src].ply;
     if (p > d.MAXPLY) { if (lane == 0) dev_error(d, DERR_PLY_POOL); return; }
     for (int i = lane; i < HIST_RING; i += 64) {
         d.hist[(size_t)dst * HIST_RING + i] = sd.hist[(size_t)src * HIST_RING + i];
@@ -389,10 +398,10 @@ __global__ __launch_bounds__(64) void k_copy_game_across(Dev d, int dst, Dev sd,
         d.rec_moves[(size_t)dst * d.MAXPLY + i] = sd.rec_moves[(size_t)src * sd.MAXPLY + i];
     if (lane == 0) {
         d.cur[dst] = sd.cur[src];
-        d.ply[dst] = p;
-        d.game_result[dst] = sd.game_result[src];
-        d.root_dead[dst] = 1;
-        d.leaf_kind[dst] = LEAF_NONE;
+        d.game[dst].ply = p;
+        d.game[dst].game_result = sd.game[src].game_result;
+        d.game[dst].root_dead = 1;
+        d.game[dst].leaf_kind = LEAF_NONE;
     }
 }
 
@@ -402,13 +411,13 @@ __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
-    if (lane == 0) { d.leaf_kind[g] = LEAF_NONE; d.path_len[g] = 0; }
-    if (d.game_result[g] != RESULT_NONE) {
-        if (lane == 0) { d.root_dead[g] = 1; d.n_nodes[g] = 0; d.root_visits[g] = 0; }
+    if (lane == 0) { d.game[g].leaf_kind = LEAF_NONE; d.game[g].path_len = 0; }
+    if (d.game[g].game_result != RESULT_NONE) {
+        if (lane == 0) { d.game[g].root_dead = 1; d.game[g].n_nodes = 0; d.game[g].root_visits = 0; }
         return;
     }
     Board b = d.cur[g];
-    const int p = d.ply[g];
+    const int p = d.game[g].ply;
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
     init_edges(d, eb, 0, mi.n, s.mv, lane);
@@ -416,13 +425,13 @@ __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
         NodeMeta m;
         m.edge0 = 0; m.nmoves = (u16)mi.n; m.nexp = 0; m.result = RESULT_NONE; m.has_s2 = 1;
         m.parent = 0; m.parent_edge = -1;
-        d.meta[nb] = m;
-        d.nb2[nb] = b;
-        d.nh2[nb] = board_hash(b);
-        d.n_nodes[g] = 1;
-        d.edge_top[g] = mi.n;
-        d.root_visits[g] = 1;                // Tree.__init__: root.visits = 1
-        d.root_dead[g] = 0;
+        d.node[nb].meta = m;
+        d.node[nb].s2 = b;
+        d.node[nb].h2 = board_hash(b);
+        d.game[g].n_nodes = 1;
+        d.game[g].edge_top = mi.n;
+        d.game[g].root_visits = 1;                // Tree.__init__: root.visits = 1
+        d.game[g].root_dead = 0;
         d.path_node[nb] = 0;
     }
     __syncthreads();
@@ -432,8 +441,8 @@ __global__ __launch_bounds__(64) void k_search_begin(Dev d, void *planes)
 __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
 {
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
-    if (d.root_dead[g]) return;
-    NodeMeta m = d.meta[(size_t)g * d.N];
+    if (d.game[g].root_dead) return;
+    NodeMeta m = d.node[(size_t)g * d.N].meta;
     gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane);
     if (lane == 0) d.counters[(size_t)g * CNT_N + CNT_EVALS] += 1;
 }
@@ -442,12 +451,12 @@ __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
 __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, const float *pol2,
                                       const float *val2)
 {
-    const int kind = uni(d.leaf_kind[g]);
+    const int kind = uni(d.game[g].leaf_kind);
     if (kind == LEAF_NONE) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     if (kind == LEAF_NEW_REPLY) { dev_error(d, DERR_STATE); return; }
-    const int leaf = uni(d.leaf_node[g]);
-    NodeMeta m = d.meta[nb + leaf];
+    const int leaf = uni(d.game[g].leaf_node);
+    NodeMeta m = d.node[nb + leaf].meta;
     double v;
     unsigned long long evals = 0;
     if (m.result != RESULT_NONE) {
@@ -458,15 +467,15 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
         evals = 1;                                     // policy/value(S2)
     }
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
-    const int plen = uni(d.path_len[g]);
+    const int plen = uni(d.game[g].path_len);
     for (int l = lane; l < plen; l += 64) {
         Edge *e = d.edge + eb + d.path_edge[nb + l];
         e->visits += 1;
         e->value = __dadd_rn(e->value, v);
     }
     if (lane == 0) {
-        d.root_visits[g] += 1;
-        d.leaf_kind[g] = LEAF_NONE;
+        d.game[g].root_visits += 1;
+        d.game[g].leaf_kind = LEAF_NONE;
         unsigned long long *c = d.counters + (size_t)g * CNT_N;
         c[CNT_SIMS] += 1;
         c[CNT_DEPTH] += plen;
@@ -480,7 +489,7 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
 __global__ __launch_bounds__(64) void k_backup(Dev d, const float *pol2, const float *val2)
 {
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
-    if (d.root_dead[g]) return;
+    if (d.game[g].root_dead) return;
     backup_pending(d, g, r, lane, pol2, val2);
 }
 
@@ -489,35 +498,35 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
 {
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
-    if (d.root_dead[g]) return;
+    if (d.game[g].root_dead) return;
     backup_pending(d, g, r, lane, pol2, val2);
 
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     const bool legacy = (d.flags & 1u) != 0;
-    const int p = uni(d.ply[g]);
+    const int p = uni(d.game[g].ply);
     int node = 0, level = 0;
     for (;;) {
-        NodeMeta m = d.meta[nb + node];
+        NodeMeta m = d.node[nb + node].meta;
         const int edge0 = uni(m.edge0), nmoves = uni(m.nmoves), nexp = uni(m.nexp);
         const int result = uni(m.result);
         if (result != RESULT_NONE) {                                   // is_terminal_state
-            if (lane == 0) { d.leaf_kind[g] = LEAF_TERMINAL_HIT; d.leaf_node[g] = node; }
+            if (lane == 0) { d.game[g].leaf_kind = LEAF_TERMINAL_HIT; d.game[g].leaf_node = node; }
             break;
         }
         if (nexp < nmoves) {                                           // not fully expanded
             const int j = nmoves - 1 - nexp;                           // list.pop(): last first
             const int edge = edge0 + j;
             const u32 mv = d.edge[eb + edge].move;
-            const int c = uni(d.n_nodes[g]);                           // wave-uniform: scalar addressing
+            const int c = uni(d.game[g].n_nodes);                           // wave-uniform: scalar addressing
             if (c >= d.N || level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
             if (lane == 0) {
-                d.meta[nb + node].nexp = (u16)(nexp + 1);
+                d.node[nb + node].meta.nexp = (u16)(nexp + 1);
                 d.path_edge[nb + level] = edge;
                 d.path_node[nb + level + 1] = (u16)c;
-                d.n_nodes[g] = c + 1;
+                d.game[g].n_nodes = c + 1;
             }
             level++;
-            Board parent = d.nb2[nb + node];
+            Board parent = d.node[nb + node].s2;
             Board s1 = apply_move(parent, mv);
             __syncthreads();                                           // path_node visible
             PosEval e = eval_position(d, g, s1, 2 * level - 1, p, p, lane, s);
@@ -525,24 +534,24 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
             cm.edge0 = 0; cm.nmoves = (u16)e.n; cm.nexp = 0; cm.result = (int8_t)e.result;
             cm.has_s2 = 0; cm.parent = (u16)node; cm.parent_edge = edge;
             if (lane == 0) {
-                d.nb1[nb + c] = e.b;
-                d.nh1[nb + c] = e.hash;
-                d.meta[nb + c] = cm;
-                d.leaf_node[g] = c;
+                d.node[nb + c].s1 = e.b;
+                d.node[nb + c].h1 = e.hash;
+                d.node[nb + c].meta = cm;
+                d.game[g].leaf_node = c;
             }
             if (e.result != RESULT_NONE) {                              // game ended on our move
                 if (lane == 0) {
-                    d.nb2[nb + c] = e.b;
-                    d.nh2[nb + c] = e.hash;
+                    d.node[nb + c].s2 = e.b;
+                    d.node[nb + c].h2 = e.hash;
                     d.edge[eb + edge].child = (u16)(c | CHILD_TERMINAL);
-                    d.leaf_kind[g] = LEAF_NEW_S1_OVER;
+                    d.game[g].leaf_kind = LEAF_NEW_S1_OVER;
                 }
             } else {
                 for (int i = lane; i < e.n; i += 64) d.s1_moves[(size_t)g * MAX_MOVES + i] = s.mv[i];
                 if (lane == 0) {
                     d.edge[eb + edge].child = (u16)c;
-                    d.s1_n[g] = e.n;
-                    d.leaf_kind[g] = LEAF_NEW_REPLY;
+                    d.game[g].s1_n = e.n;
+                    d.game[g].leaf_kind = LEAF_NEW_REPLY;
                 }
                 __syncthreads();
                 encode_position(d, g, e.b, 2 * level - 1, p, p, lane, s, planes1, r);
@@ -588,36 +597,36 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
         level++;
         node = uni(child);
     }
-    if (lane == 0) d.path_len[g] = level;
+    if (lane == 0) d.game[g].path_len = level;
 }
 
 __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *planes2)
 {
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
-    if (d.root_dead[g] || d.leaf_kind[g] != LEAF_NEW_REPLY) return;
+    if (d.game[g].root_dead || d.game[g].leaf_kind != LEAF_NEW_REPLY) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
-    const int c = uni(d.leaf_node[g]), level = uni(d.path_len[g]), n1 = uni(d.s1_n[g]), p = uni(d.ply[g]);
-    Board s1 = d.nb1[nb + c];
+    const int c = uni(d.game[g].leaf_node), level = uni(d.game[g].path_len), n1 = uni(d.game[g].s1_n), p = uni(d.game[g].ply);
+    Board s1 = d.node[nb + c].s1;
     // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
     const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
     const int bi = argmax_policy(d, r, mv1, n1, pol1, lane);
     const u32 reply = mv1[bi];
     Board s2 = apply_move(s1, reply);
     PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);
-    const int edge0 = uni(d.edge_top[g]);
+    const int edge0 = uni(d.game[g].edge_top);
     if (edge0 + e.n > d.ECAP) { dev_error(d, DERR_EDGE_POOL); return; }
     init_edges(d, eb, edge0, e.n, s.mv, lane);
     if (lane == 0) {
-        NodeMeta m = d.meta[nb + c];
+        NodeMeta m = d.node[nb + c].meta;
         m.edge0 = edge0; m.nmoves = (u16)e.n; m.nexp = 0; m.result = (int8_t)e.result; m.has_s2 = 1;
-        d.meta[nb + c] = m;
-        d.nb2[nb + c] = e.b;
-        d.nh2[nb + c] = e.hash;
-        d.n_reply[nb + c] = (u16)reply;
-        d.edge_top[g] = edge0 + e.n;
+        d.node[nb + c].meta = m;
+        d.node[nb + c].s2 = e.b;
+        d.node[nb + c].h2 = e.hash;
+        d.node[nb + c].reply = (u16)reply;
+        d.game[g].edge_top = edge0 + e.n;
         if (e.result != RESULT_NONE) d.edge[eb + m.parent_edge].child = (u16)(c | CHILD_TERMINAL);
-        d.leaf_kind[g] = LEAF_NEW_S2;
+        d.game[g].leaf_kind = LEAF_NEW_S2;
     }
     __syncthreads();
     encode_position(d, g, e.b, 2 * level, p, p, lane, s, planes2, r);
@@ -629,12 +638,12 @@ __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, in
 {
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
-    if (d.root_dead[g]) {
+    if (d.game[g].root_dead) {
         if (lane == 0) { nchild[r] = 0; root_visits[r] = 0; }
         return;
     }
-    NodeMeta m = d.meta[nb];
-    if (lane == 0) { nchild[r] = m.nexp; root_visits[r] = d.root_visits[g]; }
+    NodeMeta m = d.node[nb].meta;
+    if (lane == 0) { nchild[r] = m.nexp; root_visits[r] = d.game[g].root_visits; }
     for (int k = lane; k < m.nexp; k += 64) {
         const Edge e = d.edge[eb + m.edge0 + (m.nmoves - 1 - k)];   // children order = reverse legal
         const size_t o = (size_t)r * MAX_MOVES + k;
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(64) void k_root_children(Dev d, int32_t *nchild, in
         // then the reference's children still carry Node.prior = 1
         priors[o] = m.nexp < m.nmoves ? 1.0f : e.prior;
         moves[o] = e.move;
-        replies[o] = d.meta[nb + c].has_s2 ? d.n_reply[nb + c] : NO_MOVE;
+        replies[o] = d.node[nb + c].meta.has_s2 ? d.node[nb + c].reply : NO_MOVE;
     }
 }
 
@@ -655,32 +664,32 @@ __global__ __launch_bounds__(64) void k_advance(Dev d, const int32_t *chosen, u1
     if (lane != 0) return;
     bm[r] = NO_MOVE; am[r] = NO_MOVE;
     const int k = chosen[r];
-    if (k < 0 || d.root_dead[g]) return;
+    if (k < 0 || d.game[g].root_dead) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
-    NodeMeta m = d.meta[nb];
-    if (k >= m.nexp || d.leaf_kind[g] != LEAF_NONE) { dev_error(d, DERR_STATE); return; }
+    NodeMeta m = d.node[nb].meta;
+    if (k >= m.nexp || d.game[g].leaf_kind != LEAF_NONE) { dev_error(d, DERR_STATE); return; }
     const Edge ed = d.edge[eb + m.edge0 + (m.nmoves - 1 - k)];
     const int c = ed.child & CHILD_NONE;
-    NodeMeta cm = d.meta[nb + c];
-    const int p = d.ply[g];
+    NodeMeta cm = d.node[nb + c].meta;
+    const int p = d.game[g].ply;
     const int np = p + (cm.has_s2 ? 2 : 1);
     if (np > d.MAXPLY) { dev_error(d, DERR_PLY_POOL); return; }
     size_t hi = (size_t)g * HIST_RING + ((p + 1) & (HIST_RING - 1));
-    d.hist[hi] = d.nb1[nb + c];
-    d.hist_hash[hi] = d.nh1[nb + c];
+    d.hist[hi] = d.node[nb + c].s1;
+    d.hist_hash[hi] = d.node[nb + c].h1;
     d.rec_moves[(size_t)g * d.MAXPLY + p] = ed.move;
     bm[r] = ed.move;
     if (cm.has_s2) {
         hi = (size_t)g * HIST_RING + ((p + 2) & (HIST_RING - 1));
-        d.hist[hi] = d.nb2[nb + c];
-        d.hist_hash[hi] = d.nh2[nb + c];
-        d.rec_moves[(size_t)g * d.MAXPLY + p + 1] = d.n_reply[nb + c];
-        am[r] = d.n_reply[nb + c];
+        d.hist[hi] = d.node[nb + c].s2;
+        d.hist_hash[hi] = d.node[nb + c].h2;
+        d.rec_moves[(size_t)g * d.MAXPLY + p + 1] = d.node[nb + c].reply;
+        am[r] = d.node[nb + c].reply;
     }
-    d.cur[g] = d.nb2[nb + c];                 // node state (S1 copy when the game ended there)
-    d.ply[g] = np;
-    d.game_result[g] = cm.result;
-    d.root_dead[g] = 1;                       // the tree is consumed: fresh tree per move
+    d.cur[g] = d.node[nb + c].s2;                 // node state (S1 copy when the game ended there)
+    d.game[g].ply = np;
+    d.game[g].game_result = cm.result;
+    d.game[g].root_dead = 1;                       // the tree is consumed: fresh tree per move
 }
 
 }  // namespace crl

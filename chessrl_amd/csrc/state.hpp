@@ -5,13 +5,18 @@
 // move (agentdistributed.py:61-63) of at most N = max_sims + 1 nodes, because
 // one simulation creates at most one node (mctree.py:231-257).
 //
-//   games   cur[G]                current position (== hist ring at ply)
+//   games   game[G]               32-byte row of per-game scalars (ply, result, tree counters,
+//                                 pending-simulation state)
+//           cur[G]                current position (== hist ring at ply)
 //           hist[G][256]          ring of the last 256 positions  (encoder history,
 //           hist_hash[G][256]     fivefold repetition; python-chess move stack)
 //           rec_moves[G][P]       the game record, u16 move ids (game.py:59-66)
-//   nodes   meta[G][N]            16-byte record: edge range, expansion cursor, result
-//           nb1/nb2[G][N]         S1 (after our move) / S2 (after the stored reply)
-//           nh1/nh2[G][N]         transposition-key filter hashes of S1 / S2
+//   nodes   node[G][N]            176-byte record: 16-byte meta (edge range, expansion cursor,
+//                                 result), filter hashes and boards of S1 (after our move) and
+//                                 S2 (after the stored reply), the reply -- one record so that a
+//                                 new node is a few contiguous sectors and the kernels hold ONE
+//                                 base pointer instead of six (scalar-register pressure spilled
+//                                 26 VGPRs of k_select_expand in the array-per-field layout)
 //   edges   edge[G][ECAP]         one 24-byte record per LEGAL MOVE of a node, in python-chess
 //                                 order: child's value sum (f64), visits (i32), prior (f32),
 //                                 move (u16), child node id | terminal<<15.  A node's records
@@ -52,6 +57,26 @@ struct __attribute__((aligned(16))) NodeMeta {
 };
 static_assert(sizeof(NodeMeta) == 16, "NodeMeta must be 16 bytes");
 
+struct __attribute__((aligned(16))) NodeRow {
+    NodeMeta meta;
+    u64 h1, h2;             // transposition-key filter hashes of S1 / S2
+    Board s1, s2;           // S1 (after our move) / S2 (after the stored reply; S1 copy if the game ended there)
+    u16 reply;              // the stored reply
+    u16 pad[7];
+};
+static_assert(sizeof(NodeRow) == 176, "NodeRow must be 176 bytes");
+
+struct __attribute__((aligned(16))) GameRow {
+    int32_t ply;            // len(move_stack)
+    int32_t n_nodes, edge_top, root_visits;              // the tree of the current move
+    int32_t path_len, leaf_node, s1_n;                   // the pending simulation
+    int8_t game_result;     // Game.get_result(); RESULT_NONE = running
+    uint8_t root_dead;      // no live tree (finished game, or the tree was consumed by crl_advance)
+    uint8_t leaf_kind;      // LeafKind of the pending simulation
+    uint8_t pad;
+};
+static_assert(sizeof(GameRow) == 32, "GameRow must be 32 bytes");
+
 // One legal move of a node = one child slot (Node.value / visits / prior of mctree.py:28-37).
 struct __attribute__((aligned(8))) Edge {
     double value;           // child's value sum
@@ -71,26 +96,18 @@ struct Dev {
     u32 flags;
     int plane_fmt;                     // 0: encoders write fp16 NHWC planes, 1: 128 bit planes per position
     // games
+    GameRow *game;
     Board *cur;
-    int32_t *ply;
     Board *hist;
     u64 *hist_hash;
     u16 *rec_moves;
-    int8_t *game_result;
     // tree
-    int32_t *n_nodes, *edge_top, *root_visits;
-    uint8_t *root_dead;
-    NodeMeta *meta;
-    Board *nb1, *nb2;
-    u64 *nh1, *nh2;
-    u16 *n_reply;
+    NodeRow *node;
     Edge *edge;
     // pending simulation
-    int32_t *path_len, *path_edge, *leaf_node;
+    int32_t *path_edge;
     u16 *path_node;
-    uint8_t *leaf_kind;
     u16 *s1_moves;
-    int32_t *s1_n;
     // misc
     const u16 *lut;                    // [5][4096] move -> label index (0xFFFF = none)
     unsigned long long *counters;      // [G][CNT_N]
