@@ -7,6 +7,7 @@ within 1e-3 of the fp32 oracle (the tolerance BASELINE.json's north_star states)
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import encoder_oracle, mcts_oracle, tower_oracle
 from oracle.chess_oracle import OracleGame, move_to_uci, uci_to_move
@@ -356,6 +357,49 @@ def test_fused_trunk_matches_pytorch_trunk_activations(filters, n_boards):
             _lib.lib().crl_trunk_set_small_batch(1)
         assert torch.equal(trunk, trunk_big)
         assert (heads - heads_big).abs().max().item() <= 1e-5 * max(1.0, heads.abs().max().item())
+
+
+@pytest.mark.parametrize("n_boards", [5, 64, 1000])
+def test_mfma_dense_heads_match_the_fp32_dense_layers(n_boards):
+    """crl_heads_forward (csrc/heads.hpp: Dense(1968)+softmax, Dense(256)-relu-Dense(1)-tanh on
+    (hi, lo)-split fp16 MFMAs) against the same layers in torch fp32 on the same head activations,
+    incl. batches that are not a multiple of the 16-board blocks and the policy-only call."""
+    import ctypes
+    from chessrl_amd import _lib
+    from chessrl_amd.model import ChessModel
+    w = tower_oracle.init_weights(2, 64, seed=21, randomize_bn=True)
+    rng = np.random.default_rng(n_boards)
+    w["policy.dense.bias"] = rng.normal(0, 0.5, 1968).astype(np.float32)      # non-trivial biases
+    w["value.dense1.bias"] = rng.normal(0, 0.2, 256).astype(np.float32)
+    w["value.dense2.bias"] = np.array([0.3], np.float32)
+    model = ChessModel(weights=w)
+    hp = torch.from_numpy(np.abs(rng.normal(0, 1.5, (n_boards, 192))).astype(np.float32)).cuda()
+    hp[:, ::7] = 0                                                              # ReLU outputs: many zeros
+    n = model.net
+    with torch.no_grad():
+        ref_p = torch.softmax(n.policy_fc(hp[:, :128]), -1)
+        ref_v = torch.tanh(n.value_fc2(F.relu(n.value_fc1(hp[:, 128:])))[:, 0])
+    vp = ctypes.c_void_p
+
+    def run(pol, val):
+        rc = _lib.lib().crl_heads_forward(
+            vp(torch.cuda.current_stream().cuda_stream), vp(hp.data_ptr()), n_boards,
+            vp(model._pol_wp.data_ptr()), vp(model._pol_bias.data_ptr()), vp(model._val_w1p.data_ptr()),
+            vp(model._val_b1.data_ptr()), vp(model._val_w2.data_ptr()), vp(pol.data_ptr()),
+            vp(val.data_ptr() if val is not None else None))
+        assert rc == 0
+        torch.cuda.synchronize()
+
+    pol = torch.full((n_boards + 3, 1968), -7.0, device="cuda")                 # guard rows stay untouched
+    val = torch.full((n_boards + 3,), -7.0, device="cuda")
+    run(pol, val)
+    assert (pol[:n_boards] - ref_p).abs().max().item() <= 1e-6
+    assert (val[:n_boards] - ref_v).abs().max().item() <= 1e-6
+    assert (pol[:n_boards].sum(1) - 1).abs().max().item() <= 1e-5
+    assert (pol[n_boards:] == -7.0).all() and (val[n_boards:] == -7.0).all()
+    pol2 = torch.zeros_like(pol)
+    run(pol2, None)                                                             # S1 evaluations: no value head
+    assert torch.equal(pol2[:n_boards], pol[:n_boards])
 
 
 def _bits_from_planes(planes):
