@@ -78,12 +78,29 @@ def build(force=False, verbose=False, tuning=False):
     so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
     if not force and not is_stale(so, extra):
         return so
-    cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", so, os.path.join(_CSRC, "api.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    with open(_stamp(so), "w") as f:
-        f.write(source_hash(extra) + "\n")
+    # several ranks of one node may arrive here together (torchrun starts one process per GPU):
+    # one compiles, the others wait on the lock and find the library fresh; the library and its
+    # stamp appear atomically (rename), so nobody ever loads a half-written file
+    import fcntl
+    with open(so + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale(so, extra):
+            return so
+        tmp = "%s.tmp.%d" % (so, os.getpid())
+        cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", tmp, os.path.join(_CSRC, "api.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            if os.path.exists(_stamp(so)):
+                os.remove(_stamp(so))
+            os.replace(tmp, so)
+            with open(_stamp(so) + ".tmp", "w") as f:
+                f.write(source_hash(extra) + "\n")
+            os.replace(_stamp(so) + ".tmp", _stamp(so))
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return so
 
 

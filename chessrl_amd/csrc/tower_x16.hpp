@@ -202,6 +202,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int base0 = lds_base + board * G::ABOARD + (pbase + r) * G::AROW + q * 16;   // block 0's own row
     const int zero_q = lds_base + G::ZERO_OFF + q * 16;
     const int act_row0 = board * G::ABOARD + (pbase + r) * G::AROW;    // the lane's row in block 0
+    // which lanes have an on-board neighbour to the left / right, and (per block) above / below
+    const unsigned long long xm_left = __ballot(px >= 1), xm_right = __ballot(px <= 6);
+    unsigned long long ym_up[PT], ym_down[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) {
+        ym_up[pt] = __ballot(py0 + 2 * pt >= 1);
+        ym_down[pt] = __ballot(py0 + 2 * pt <= 6);
+    }
     // Weight fragment address: row o = obase + 16 ct + r of a tile plane, quarter q.  The swizzle
     // (-(o >> 2)) & 3 does not depend on ct (16 ct >> 2 is a multiple of 4), so ONE per-lane address
     // serves every channel block, sub-step and tile of a tap through the immediate offset
@@ -376,11 +384,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             const int choff = (v & ((1 << hshift) - 1)) * 256;
             const int zrow = zero_q + ((r + shift) & 15) * G::AROW + choff;
             const int inb = base0 + shift * G::AROW + choff;
-            const bool xok = (unsigned)(px + dx) < 8u;
+            // on-board tests as wave masks in SGPRs (computed once per kernel): per block only a
+            // scalar AND, one add and one select remain
+            const unsigned long long xm = dx < 0 ? xm_left : (dx > 0 ? xm_right : ~0ull);
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) {
-                const bool ok = xok && (unsigned)(py0 + 2 * pt + dy) < 8u;
-                dst[pt] = ok ? inb + pt * 16 * G::AROW : zrow;
+                const unsigned long long m = xm & (dy < 0 ? ym_up[pt] : (dy > 0 ? ym_down[pt] : ~0ull));
+                const int row = inb + pt * 16 * G::AROW;
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst[pt]) : "v"(zrow), "v"(row), "s"(m));
             }
         };
         vtap_rows(0, ab[1]);
@@ -413,9 +424,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) {
-                    half4 o16;
+                    half4 o16;                           // convert, then ReLU on packed halves
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)fmaxf(acc[pt][ct][j], 0.f);
+                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)acc[pt][ct][j];
+                    o16 = __builtin_elementwise_max(o16, half4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0});
                     store_block(pt, ct, o16);
                 }
         } else if (kind == 2) {                         // conv2: + skip, ReLU, new skip
@@ -424,9 +436,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) {
                     half4 o16;
+                    const f32x4v sum = acc[pt][ct] + res[pt][ct];          // packed fp32 adds
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const float v = fmaxf(acc[pt][ct][j] + res[pt][ct][j], 0.f);
+                        const float v = fmaxf(sum[j], 0.f);
                         res[pt][ct][j] = v;
                         o16[j] = (_Float16)v;
                     }

@@ -34,6 +34,9 @@ static double run(const char *name, kern_t k, int lds, int boards_per_wg, int F,
         printf("ran %s x3\n", name);
         return 0;
     }
+    const char *match = getenv("MATCH");                  // A/B runs: time just the kernels whose label matches
+    if (match && !strstr(name, match)) return 0;
+    if (match && ref && ref->size() != (size_t)boards * 192) ref = nullptr;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     CK(hipMemset(b.head_out, 0, (size_t)boards * 192 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -95,6 +98,7 @@ static Bufs make(int F, int blocks, int boards)
 template <int F, int NB>
 static void stamps(const Bufs &b, int blocks, int boards)
 {
+    if (getenv("MATCH")) return;
     typedef Geo16<F, NB> G;
     kern_t k = k_trunk_x16<F, NB, 1, 2>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
