@@ -82,6 +82,93 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int iters)
     out[blockIdx.x * 512 + tid] = s;
 }
 
+// SHAPE 2: 16x16x32, ONE wave per SIMD (256-thread workgroup, LDS sized so that only one fits a CU),
+// 8x4 blocks per wave (128 positions x 64 channels): 12 reads per 32 MFMAs instead of 8 per 16.
+// SHAPE 3: as 2 with 8x8 blocks (128 x 128, 256 accumulator registers): 16 reads per 64 MFMAs.
+template <int PB, int CB>
+__global__ __launch_bounds__(256, 1) void kbig(float *out, int iters)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char raw[];
+    lds_byte *lds = (lds_byte *)raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        unsigned s = 1234567u + tid * 2654435761u;
+        for (int i = tid; i < 65536 / 2; i += 256) {
+            s = s * 1664525u + 1013904223u;
+            ((__attribute__((address_space(3))) _Float16 *)lds)[i] = (_Float16)((((int)(s >> 20) & 1023) - 512) * (1.0f / 4096.0f));
+        }
+        __syncthreads();
+    }
+    f32x4 acc[PB][CB];
+    for (int a = 0; a < PB; a++) for (int b = 0; b < CB; b++) for (int i = 0; i < 4; i++) acc[a][b][i] = 0.f;
+    const lds_byte *base = lds + wave * 4096 + (lane & 15) * 272 + (lane >> 4) * 16;
+    half8 x[2][PB], w[2][CB];
+    for (int j = 0; j < PB; j++) x[0][j] = rd(base + j * 4352);
+    for (int j = 0; j < CB; j++) w[0][j] = rd(base + 17408 + j * 4352);
+#define STEPBIG(CUR, NXT, IT)                                                                       \
+    {                                                                                               \
+        const int off = (((IT) + 1) & 3) * 64;                                                      \
+        for (int j = 0; j < PB; j++) x[NXT][j] = rd(base + off + (j & 7) * 4352);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        for (int a = 0; a < PB / 2; a++) for (int b = 0; b < CB; b++)                               \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[CUR][b], x[CUR][a], acc[a][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        for (int j = 0; j < CB; j++) w[NXT][j] = rd(base + 17408 + off + (j & 7) * 4352);           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        for (int a = PB / 2; a < PB; a++) for (int b = 0; b < CB; b++)                              \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[CUR][b], x[CUR][a], acc[a][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+    for (int it = 0; it < iters; it += 2) {
+        STEPBIG(0, 1, it)
+        STEPBIG(1, 0, it + 1)
+    }
+    float s = 0;
+    for (int a = 0; a < PB; a++) for (int b = 0; b < CB; b++) for (int i = 0; i < 4; i++) s += acc[a][b][i];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+// SHAPE 4: 16x16x32, 4x4 blocks, 2 waves per SIMD, operands stay in registers (no LDS read in the loop)
+__global__ __launch_bounds__(512, 1) void kreg(float *out, int iters)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char raw[];
+    lds_byte *lds = (lds_byte *)raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fill(lds, tid);
+    f32x4 acc[4][4];
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) for (int i = 0; i < 4; i++) acc[a][b][i] = 0.f;
+    const lds_byte *base = lds + wave * 4096 + (lane & 15) * 272 + (lane >> 4) * 16;
+    half8 x[4], w[4];
+    for (int j = 0; j < 4; j++) { x[j] = rd(base + j * 4352); w[j] = rd(base + 17408 + j * 4352); }
+    for (int it = 0; it < iters; it++) {
+        for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[b], x[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0;
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) for (int i = 0; i < 4; i++) s += acc[a][b][i];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <typename K> double run_k(K kern, int threads, int lds, double macs_per_wave_step, float *out, const char *tag, int iters)
+{
+    const int grid = 256 * 4;
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double best = 1e9;
+    for (int r = 0; r < 3; r++) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, out, iters);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flops = (double)grid * (threads / 64) * iters * macs_per_wave_step * 2;
+    printf("%s: %.3f ms  %.0f TFLOP/s (%.3f of 2500)\n", tag, best, flops / best / 1e9, flops / best / 1e9 / 2500);
+    return best;
+}
+
 template <int SHAPE> double run(float *out, const char *tag, int iters)
 {
     const int grid = 256 * 4;
@@ -107,6 +194,9 @@ int main()
     for (int rep = 0; rep < 2; rep++) {
         run<0>(out, "32x32x16 f16, 2x2 tiles, 8 MFMA + 8 ds_read_b128 per K=32", 6000);
         run<1>(out, "16x16x32 f16, 4x4 tiles, 16 MFMA + 8 ds_read_b128 per K=32", 6000);
+        run_k(kbig<8, 4>, 256, 100 * 1024, 128.0 * 64 * 32, out, "16x16x32, ONE wave/SIMD, 8x4 tiles, 32 MFMA + 12 reads", 6000);
+        run_k(kbig<8, 8>, 256, 100 * 1024, 128.0 * 128 * 32, out, "16x16x32, ONE wave/SIMD, 8x8 tiles, 64 MFMA + 16 reads", 3000);
+        run_k(kreg, 512, 100 * 1024, 64.0 * 64 * 32, out, "16x16x32, 4x4 tiles, operands in registers (no LDS reads)", 6000);
     }
     return 0;
 }
