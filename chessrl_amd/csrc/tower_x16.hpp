@@ -16,8 +16,9 @@
 //     lanes of a ds_read_b128 group -- 8 rows at quarter q, 8 at q+1 -- then cover all 64 banks;
 //   * weight tiles keep their global format ([F out][KT in] rows); the 32-channel tiles of the
 //     256-filter tower use the chunk swizzle (-(row >> 2)) & 3 in LDS;
-//   * the accumulator of block (pt, ct) holds, per lane, 4 consecutive channels 16 ct + 4 q + j of
-//     position 16 pt + r: the epilogue still writes 8-byte words into the LDS image in place;
+//   * the accumulator of block (pt, ct) holds, per lane, 4 consecutive channels of position
+//     16 pt + r; channel blocks 2g and 2g+1 are interleaved (Geo16::chan_of) so that a lane's 4 + 4
+//     values are 8 consecutive channels and the epilogue writes 16-byte words in place;
 //   * the head convolutions reduce 4 CG partial sums per output (4 lane quarters x CG waves).
 #pragma once
 #include "tower_gen.hpp"
@@ -55,6 +56,23 @@ struct Geo16 {
     // rows at quarter q, 8 at q+1) cover all 64 banks, and the sub-step is an immediate offset.
     static constexpr int WPLANE = F * 64;
     __device__ static int wswz(int row) { return (0 - (row >> 2)) & 3; }
+    // Which output channel accumulator row i (= 4 q + j) of channel block ct computes, relative to
+    // the wave's first channel: blocks 2g and 2g+1 interleave in units of 4, so that a lane's 4 + 4
+    // values of the two blocks are 8 CONSECUTIVE channels 32 g + 8 q .. + 8 and the epilogue writes
+    // them as one 16-byte word (half the LDS write instructions, and conflict-free like the reads:
+    // same (row, 16-byte quarter) lane map).  The permutation is applied where weight rows enter
+    // LDS (source row of the DMA); the global weight image keeps its natural channel order.
+    __host__ __device__ static constexpr int chan_of(int ct, int i)
+    {
+        return 32 * (ct >> 1) + 8 * (i >> 2) + 4 * (ct & 1) + (i & 3);
+    }
+    // LDS weight-image row (16 ct + i within a wave's 16 CT rows) -> global row holding its channel
+    __device__ static int src_row(int row)
+    {
+        constexpr int W = 16 * CT;
+        const int in = row & (W - 1);
+        return (row & ~(W - 1)) + chan_of(in >> 4, in & 15);
+    }
 };
 
 // stage weight tile t (global format [F out][KT in]) into ring slot t & 3 as the plane image above.
@@ -79,7 +97,7 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
             const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
             const int row = rem >> 2, phys = rem & 3;
             const int chunk = phys ^ G::wswz(row);
-            const unsigned off = (unsigned)(row * G::WROW + ksub * 64 + chunk * 16);
+            const unsigned off = (unsigned)(G::src_row(row) * G::WROW + ksub * 64 + chunk * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src + off),
                 (__attribute__((address_space(3))) void *)(lds + dst0 + j * 4096), 16, 0, 0);
@@ -92,7 +110,7 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
             const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
             const int row = rem >> 2, phys = rem & 3;
             const int chunk = phys ^ G::wswz(row);
-            const unsigned off = (unsigned)(row * G::WROW + ksub * 64 + chunk * 16);
+            const unsigned off = (unsigned)(G::src_row(row) * G::WROW + ksub * 64 + chunk * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src + off),
                 (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
@@ -107,9 +125,14 @@ template <class G, int F>
 __device__ inline void stage_bias_x16(const float *bias, lds_byte *lds, int conv, int lane, int wave_u)
 {
     if (wave_u >= F / 64) return;
-    const float *src = bias + (size_t)conv * F + wave_u * 64;
+    // uniform base + unsigned 32-bit lane offset: the SGPR-base addressing form, no 64-bit lane address to keep
+    // (the base goes through readfirstlane so that hipcc cannot fold the lane offset into a hoisted,
+    // and then spilled, 64-bit per-lane address)
+    const unsigned long long a = reinterpret_cast<unsigned long long>(bias + (size_t)conv * F + wave_u * 64);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(((unsigned long long)hi << 32) | lo);
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void *)(src + lane),
+        (const __attribute__((address_space(1))) void *)(src + (unsigned)(lane * 4)),
         (__attribute__((address_space(3))) void *)(lds + G::BIAS_OFF + (conv & 1) * F * 4 + wave_u * 256), 4, 0, 0);
 }
 
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             const f32x4 bv = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(
-                lds + G::BIAS_OFF + (conv & 1) * F * 4 + (obase + 16 * ct + 4 * q) * 4);
+                lds + G::BIAS_OFF + (conv & 1) * F * 4 + (obase + G::chan_of(ct, 0) + 8 * q) * 4);
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) acc[pt][ct] = f32x4v{bv[0], bv[1], bv[2], bv[3]};
         }
@@ -415,48 +438,60 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         // partner wave's MFMAs for issue slots): stem = linear (no BN, no activation,
         // model.py:33-34); conv1 = ReLU, skip stream untouched; conv2 = + skip, ReLU, new skip
         const int kind = conv == 0 ? 0 : ((conv & 1) ? 1 : 2);
-        auto store_block = [&](int pt, int ct, const half4 &o16) {
-            *reinterpret_cast<__attribute__((address_space(3))) half4 *>(
-                lds + act_row0 + pt * 16 * G::AROW + (obase + 16 * ct + 4 * q) * 2) = o16;
+        // channel blocks 2g, 2g+1 of a position block: 8 consecutive channels per lane, one 16-byte write
+        auto store_pair = [&](int pt, int g, const half4 &lo, const half4 &hi) {
+            *reinterpret_cast<__attribute__((address_space(3))) half8 *>(
+                lds + act_row0 + pt * 16 * G::AROW + (obase + 32 * g + 8 * q) * 2) =
+                half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
+        const half4 zero4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
         if (kind == 1) {                                // conv1 of a block: ReLU, skip stream untouched
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++)
+            for (int g = 0; g < CT / 2; g++)
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) {
-                    half4 o16;                           // convert, then ReLU on packed halves
+                    half4 o16[2];                        // convert, then ReLU on packed halves
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o16[j] = (_Float16)acc[pt][ct][j];
-                    o16 = __builtin_elementwise_max(o16, half4{(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0});
-                    store_block(pt, ct, o16);
+                    for (int h = 0; h < 2; h++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) o16[h][j] = (_Float16)acc[pt][2 * g + h][j];
+                        o16[h] = __builtin_elementwise_max(o16[h], zero4);
+                    }
+                    store_pair(pt, g, o16[0], o16[1]);
                 }
         } else if (kind == 2) {                         // conv2: + skip, ReLU, new skip
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++)
+            for (int g = 0; g < CT / 2; g++)
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) {
-                    half4 o16;
-                    const f32x4v sum = acc[pt][ct] + res[pt][ct];          // packed fp32 adds
+                    half4 o16[2];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float v = fmaxf(sum[j], 0.f);
-                        res[pt][ct][j] = v;
-                        o16[j] = (_Float16)v;
+                    for (int h = 0; h < 2; h++) {
+                        const int ct = 2 * g + h;
+                        const f32x4v sum = acc[pt][ct] + res[pt][ct];      // packed fp32 adds
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float v = fmaxf(sum[j], 0.f);
+                            res[pt][ct][j] = v;
+                            o16[h][j] = (_Float16)v;
+                        }
                     }
-                    store_block(pt, ct, o16);
+                    store_pair(pt, g, o16[0], o16[1]);
                 }
         } else {                                        // stem: linear
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++)
+            for (int g = 0; g < CT / 2; g++)
 #pragma unroll
                 for (int pt = 0; pt < PT; pt++) {
-                    half4 o16;
+                    half4 o16[2];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        res[pt][ct][j] = acc[pt][ct][j];
-                        o16[j] = (_Float16)acc[pt][ct][j];
-                    }
-                    store_block(pt, ct, o16);
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            res[pt][2 * g + h][j] = acc[pt][2 * g + h][j];
+                            o16[h][j] = (_Float16)acc[pt][2 * g + h][j];
+                        }
+                    store_pair(pt, g, o16[0], o16[1]);
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -480,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             const int p = pbase + 16 * pt + r;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
-                const int o0 = obase + 16 * ct + 4 * q;
+                const int o0 = obase + G::chan_of(ct, 0) + 8 * q;
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; j++) v[j] = res[pt][ct][j];
@@ -500,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             for (int k = 0; k < 3; k++) part[pt][k] = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
-            const int o0 = obase + 16 * ct + 4 * q;
+            const int o0 = obase + G::chan_of(ct, 0) + 8 * q;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(head_w + k * F + o0);
