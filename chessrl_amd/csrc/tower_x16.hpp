@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
-    static_assert(!PAIR || ((F == 128 || F == 256) && ALT == 0), "pair publishing: even tile counts per layer");
+    static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2)), "pair publishing: even tile counts per layer");
     static_assert(G::lds_bytes(PAIR ? 5 : PIPE_RING) <= 160 * 1024, "LDS budget");
     stage_bias_x16<G, F>(bias, lds, 0, lane, wave_u);   // oldest transfer: landed when tile 0 has
     stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u, PAIR ? 0 : -1);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     constexpr int HP = PT / 2;                          // position blocks per half sub-step
 
     constexpr bool STAMP = ALT == 2;                    // harness diagnostic: in-kernel cycle stamps
-    unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0, t_ba = 0, t_wr = 0;
+    unsigned long long t_loop = 0, t_epi = 0, t_begin = 0, t_mark = 0, t_ba = 0, t_wr = 0, t_vm = 0, t_sb = 0;
     if constexpr (STAMP) { t_begin = __builtin_amdgcn_s_memtime(); t_mark = t_begin; }
     int t = 0;                                          // tile of the K-step being computed
     int slot_tap = 0;                                   // PAIR: ring slot (t mod 5) of the tap's first tile
@@ -324,9 +324,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                         // start of the last sub-step of an odd tile t: tiles t+1, t+2 (moved at the
                         // previous sync, the only transfers in flight) are published; tiles <= t-1
                         // are dead and their slots take tiles t+3, t+4
+                        unsigned long long s0 = 0, s1 = 0;
+                        if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();
                         wait_vmcnt<0>();
+                        if constexpr (STAMP) { s1 = __builtin_amdgcn_s_memtime(); t_vm += s1 - s0; }
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (STAMP) t_sb += __builtin_amdgcn_s_memtime() - s1;
                         if (!bias_staged) {
                             bias_staged = true;
                             if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
@@ -338,6 +342,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 } else if constexpr (s == G::SPT - 1) {
                     // publish tile t+1 before the half that prefetches its first fragments;
                     // recycle tile t-1's slot
+                    unsigned long long s0 = 0, s1 = 0;
+                    if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();
                     if constexpr (ALT == 1) {
                         // tile t+1 was moved by the half with (t+1) & 1, three syncs ago, and is
                         // the only transfer that half has in flight
@@ -346,8 +352,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                         if (t + 2 < n_tiles) wait_vmcnt<G::GL>();
                         else wait_vmcnt<0>();
                     }
+                    if constexpr (STAMP) { s1 = __builtin_amdgcn_s_memtime(); t_vm += s1 - s0; }
                     if constexpr (ALT != 4 && ALT != 5) __builtin_amdgcn_s_barrier();   // 4, 5: timing only
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (STAMP) t_sb += __builtin_amdgcn_s_memtime() - s1;
                     if (!bias_staged) {
                         bias_staged = true;
                         if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
@@ -501,10 +509,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         if constexpr (STAMP) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_epi += now - t_mark; t_mark = now; }
     }
     if constexpr (STAMP) {
-        // per wave: [loop cycles, epilogue cycles, cycles before the first conv, total so far]
+        // per wave: [loop cycles, epilogue cycles, epilogue phases, total, loop cycles waiting for weight DMA, at the tile barrier]
         if (lane == 0 && out) {
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out) + ((size_t)blockIdx.x * 8 + wave) * 4;
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out) + ((size_t)blockIdx.x * 8 + wave) * 6;
             dbg[0] = t_loop; dbg[1] = t_epi; dbg[2] = (t_ba << 32) | (t_wr & 0xffffffffull); dbg[3] = __builtin_amdgcn_s_memtime() - t_begin;
+            dbg[4] = t_vm; dbg[5] = t_sb;
         }
         return;
     }

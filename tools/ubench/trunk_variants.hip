@@ -95,29 +95,35 @@ static Bufs make(int F, int blocks, int boards)
     return b;
 }
 
-template <int F, int NB>
+template <int F, int NB, int PAIR = 0>
 static void stamps(const Bufs &b, int blocks, int boards)
 {
     if (getenv("MATCH")) return;
     typedef Geo16<F, NB> G;
-    kern_t k = k_trunk_x16<F, NB, 1, 2>;
-    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    kern_t k = k_trunk_x16<F, NB, 1, 2, PAIR>;
+    const int lds = G::lds_bytes(PAIR ? 5 : 4);
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nwg = boards / NB;
-    unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)nwg * 8 * 4 * 8));
+    unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)nwg * 8 * 6 * 8));
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL(k, dim3(nwg), dim3(512), G::LDS_BYTES, 0, b.planes, b.wts, b.bias, (float *)dbg, blocks, b.head_w, b.head_b, b.head_out);
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, 0, b.planes, b.wts, b.bias, (float *)dbg, blocks, b.head_w, b.head_b, b.head_out);
     CK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h((size_t)nwg * 32);
+    std::vector<unsigned long long> h((size_t)nwg * 48);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double loop = 0, epi = 0, tot = 0, ba = 0, wr = 0;
-    for (int i = 0; i < nwg * 8; i++) { loop += h[i * 4]; epi += h[i * 4 + 1]; tot += h[i * 4 + 3]; ba += (double)(h[i * 4 + 2] >> 32); wr += (double)(h[i * 4 + 2] & 0xffffffffull); }
+    double loop = 0, epi = 0, tot = 0, ba = 0, wr = 0, vm = 0, sb = 0;
+    for (int i = 0; i < nwg * 8; i++) {
+        loop += h[i * 6]; epi += h[i * 6 + 1]; tot += h[i * 6 + 3]; ba += (double)(h[i * 6 + 2] >> 32); wr += (double)(h[i * 6 + 2] & 0xffffffffull);
+        vm += h[i * 6 + 4]; sb += h[i * 6 + 5];
+    }
     const int n = nwg * 8, convs = 1 + 2 * blocks;
     const double mf = (F == 64 ? (4.0 + 2.0 * blocks * 2) : F == 128 ? 4.0 * convs : (4.0 + 2.0 * blocks * 8)) * 9 * (G::PT * G::CT) * 16 * 2;
-    printf("stamps x16<%d,%d>: per wave: main loops %.0f cycles (MFMA-paced minimum at 2 waves/SIMD %.0f), epilogues %.0f (%.0f per conv), "
-           "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, loop / n, mf, epi / n, epi / n / convs, tot / n,
+    printf("stamps x16<%d,%d%s>: per wave: main loops %.0f cycles (MFMA-paced minimum at 2 waves/SIMD %.0f), epilogues %.0f (%.0f per conv), "
+           "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, PAIR ? ", pair sync" : "", loop / n, mf, epi / n, epi / n / convs, tot / n,
            loop / tot, epi / tot);
     printf("   epilogue phases per conv: wait at the first barrier %.0f, convert + LDS writes %.0f, second barrier %.0f cycles\n",
            ba / n / convs, wr / n / convs, (epi - ba - wr) / n / convs);
+    printf("   inside the loops: waiting for the weight DMA (vmcnt) %.0f cycles, at the tile barrier %.0f (incl. 2 stamp reads per sync)\n", vm / n, sb / n);
+    CK(hipFree(dbg));
 }
 
 int main(int argc, char **argv)
@@ -135,6 +141,7 @@ int main(int argc, char **argv)
         run("k_trunk_x16<128,4,1,1> alt issuer", k_trunk_x16<128, 4, 1, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,4,1> again", k_trunk_x16<128, 4, 1>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         stamps<128, 4>(b, 10, boards);
+        stamps<128, 4, 1>(b, 10, boards);
         run("  x16<128,4> no staging (timing)", k_trunk_x16<128, 4, 1, 3>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("  x16<128,4> no barrier (timing)", k_trunk_x16<128, 4, 1, 4>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("  x16<128,4> neither (timing)", k_trunk_x16<128, 4, 1, 5>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
@@ -149,6 +156,7 @@ int main(int argc, char **argv)
         run("k_trunk_gen<256,2,1> again", k_trunk_gen<256, 2, 1>, G::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("k_trunk_x16<256,2,1> 16x16x32", k_trunk_x16<256, 2, 1>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         stamps<256, 2>(b, 20, boards);
+        stamps<256, 2, 1>(b, 20, boards);
         run("  x16<256,2> no staging (timing)", k_trunk_x16<256, 2, 1, 3>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("  x16<256,2> no barrier (timing)", k_trunk_x16<256, 2, 1, 4>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
         run("  x16<256,2> neither (timing)", k_trunk_x16<256, 2, 1, 5>, Geo16<256, 2>::LDS_BYTES, 2, 256, 20, boards, 5, b, out, &ref);
