@@ -181,16 +181,15 @@ def profile_phases(run, n):
     for _ in range(max(0, run.sims // 2 - n)):
         eng.step()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
-    c = eng.ctx
     for i in range(n):
         ev[i][0].record()
-        c.sim_select_expand(eng.pol_s2.data_ptr(), eng.val_s2.data_ptr(), eng.planes_s1.data_ptr())
+        eng.phase_select_expand()
         ev[i][1].record()
-        eng._eval_into(eng.planes_s1, eng.pol_s1, None)
+        eng.phase_tower_s1()
         ev[i][2].record()
-        c.sim_reply(eng.pol_s1.data_ptr(), eng.planes_s2.data_ptr())
+        eng.phase_reply()
         ev[i][3].record()
-        eng._eval_into(eng.planes_s2, eng.pol_s2, eng.val_s2)
+        eng.phase_tower_s2()
         ev[i][4].record()
     torch.cuda.synchronize()
     names = ["select_expand", "tower_s1", "reply", "tower_s2"]
@@ -361,7 +360,7 @@ def main():
         branch = d["branch_sum"] / nodes
         shape = "%d boards, %d blocks x %d filters" % (G, B, F)
         # ---- dominant kernel (MFMA-bound) ----------------------------------------------------
-        tower_ms = event_time_ms(lambda: model.forward_into(eng.planes_s2, eng.pol_s2, eng.val_s2), 20)
+        tower_ms = event_time_ms(eng.phase_tower_s2, 20)     # trunk + both heads, as the step runs them
         tower_flops = 2.0 * model.macs_per_eval() * G
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         if model.fused:
@@ -397,13 +396,15 @@ def main():
         # ---- hand-written HIP search kernels (HBM-bound): select+expand and reply -----------
         # algorithmic bytes per simulation, SURVEY.md section 8d with the measured d and b;
         # with the fused trunk the encoders hand over 1-KiB plane bitboards (expanded on chip); any
-        # other evaluator gets 16-KiB fp16 planes.  Policy vectors are materialised (+2*b*4 B gathered)
+        # other evaluator gets 16-KiB fp16 planes.  With the HIP heads only the legal moves' priors
+        # exist (2 x b x (2 B label + 4 B prior written + 4 B read)); else full policy vectors
         plane_bytes = 1024.0 if eng.bitplanes else 16384.0      # per evaluated position (S1 and S2)
         tree_bytes = 2400.0 + 20.0 * depth * branch + 2 * plane_bytes
         ph = profile_phases(run, 16)
         tree_ms = ph["select_expand"] + ph["reply"]
         t_traffic, t_src = pmc_traffic("k_select_expand + k_reply",
-                                       "%d games, %s planes" % (G, "bit" if eng.bitplanes else "fp16"))
+                                       "%d games, %s planes, %s" % (G, "bit" if eng.bitplanes else "fp16",
+                                                                    "legal priors" if eng.legal_priors else "full policies"))
         tree = {"bound": "hbm", "kernel": "k_select_expand + k_reply (one simulation x %d games)" % G,
                 "achieved": tree_bytes * G / tree_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS,
@@ -422,6 +423,7 @@ def main():
                                    "Dirichlet noise on" % (cfg_name, G, a.sims, B, F),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
+                       "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",
                        "tower_precision": getattr(model, "precision", a.dtype),
                        "parallelism": "games sharded, no collective on the hot path"},
             "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,

@@ -46,12 +46,14 @@ FLAG_NUMPY_LEGACY = 1
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "crl_create", "crl_destroy", "crl_set_stream", "crl_sync", "crl_last_error", "crl_max_games",
-    "crl_max_sims", "crl_set_window", "crl_set_plane_format", "crl_copy_game", "crl_copy_game_from", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
+    "crl_max_sims", "crl_set_window", "crl_set_plane_format", "crl_set_policy_format", "crl_eval_labels",
+    "crl_copy_game", "crl_copy_game_from", "crl_uci_label_moves", "crl_reset_games", "crl_set_positions",
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_push_sequences", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
     "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch", "crl_heads_forward",
+    "crl_heads_forward_legal",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -171,6 +173,9 @@ def lib():
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_forward_legal.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_set_policy_format.argtypes = [vp, i32]
+    L.crl_eval_labels.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:
@@ -230,6 +235,18 @@ class Context(object):
         """Later calls act on slots [first, first+count); arrays become `count` rows."""
         self._ck(self._L.crl_set_window(self._h, first, count), "crl_set_window")
         self.G = count
+
+    def set_policy_format(self, legal):
+        """legal=True: the simulation entry points take priors[row][256] of the legal moves
+        (CRL_POLICY_LEGAL) instead of full policy[row][1968] rows."""
+        self._ck(self._L.crl_set_policy_format(self._h, 1 if legal else 0), "crl_set_policy_format")
+
+    def eval_labels(self, which):
+        """(labels, counts) device addresses for the position tower call `which` evaluates
+        (0: S1 after sim_select_expand, 1: S2 after sim_reply); rows are window-relative."""
+        lab, cnt = ctypes.c_void_p(), ctypes.c_void_p()
+        self._ck(self._L.crl_eval_labels(self._h, which, ctypes.byref(lab), ctypes.byref(cnt)), "crl_eval_labels")
+        return lab.value, cnt.value
 
     def set_plane_format(self, bits):
         """Encoders write fp16 NHWC planes (False, default) or 128 plane bitboards per position (True)."""

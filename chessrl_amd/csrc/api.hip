@@ -169,6 +169,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     d.flags = flags;
     d.g0 = 0;
     d.plane_fmt = CRL_PLANES_F16;
+    d.policy_fmt = CRL_POLICY_FULL;
     ctx->W = max_games;
     const size_t G = d.G, GN = G * d.N, GE = G * (size_t)d.ECAP;
     bool ok = true;
@@ -180,6 +181,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     AN(d.edge, GE);
     AN(d.path_edge, GN); AN(d.path_node, GN);
     A(d.s1_moves, G * MAX_MOVES);
+    A(d.lab_s1, G * MAX_MOVES); A(d.lab_s2, G * MAX_MOVES); A(d.lab_n1, G); A(d.lab_n2, G);
     A(d.counters, G * CNT_N); A(d.err, 1);
     A(ctx->t_moves, G * MAX_MOVES); A(ctx->t_moves2, G * MAX_MOVES); A(ctx->t_i32a, G * MAX_MOVES);
     A(ctx->t_i32b, G); A(ctx->t_i32c, G); A(ctx->t_f64, G * MAX_MOVES); A(ctx->t_f32, G * MAX_MOVES);
@@ -252,6 +254,23 @@ int crl_set_plane_format(crl_ctx *ctx, int format)
     if (!ctx || (format != CRL_PLANES_F16 && format != CRL_PLANES_BITS))
         return fail(ctx, CRL_ERR_ARG, "crl_set_plane_format: bad argument");
     ctx->d.plane_fmt = format;
+    return CRL_OK;
+}
+
+int crl_set_policy_format(crl_ctx *ctx, int format)
+{
+    if (!ctx || (format != CRL_POLICY_FULL && format != CRL_POLICY_LEGAL))
+        return fail(ctx, CRL_ERR_ARG, "crl_set_policy_format: bad argument");
+    ctx->d.policy_fmt = format;
+    return CRL_OK;
+}
+
+int crl_eval_labels(crl_ctx *ctx, int which, const uint16_t **dev_labels, const int32_t **dev_counts)
+{
+    if (!ctx || (which != 0 && which != 1) || !dev_labels || !dev_counts)
+        return fail(ctx, CRL_ERR_ARG, "crl_eval_labels: bad argument");
+    *dev_labels = which ? ctx->d.lab_s2 : ctx->d.lab_s1;
+    *dev_counts = which ? ctx->d.lab_n2 : ctx->d.lab_n1;
     return CRL_OK;
 }
 
@@ -693,6 +712,34 @@ int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boar
         hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
                            (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
                            (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
+    if (dev_value_out_f32)
+        hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
+                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,
+                           (const float *)dev_value_b1_f32, (const float *)dev_value_w2b2_f32,
+                           (float *)dev_value_out_f32);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                            const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                            const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                            const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
+                            const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32)
+{
+    if (!dev_head_act_f32 || n_boards < 1 || !dev_policy_wp_f16 || !dev_policy_bias_f32 || !dev_priors_out_f32 ||
+        !dev_labels || !dev_counts ||
+        (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
+        return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward_legal: bad argument");
+    auto kern = crl_heads::k_policy_head<1, true>;
+    hipError_t ea = allow_big_lds((const void *)kern, crl_heads::LEGAL_LDS_BYTES);
+    if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+    const unsigned blocks = (unsigned)((n_boards + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), crl_heads::LEGAL_LDS_BYTES, (hipStream_t)hip_stream,
+                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
+                       (const float *)dev_policy_bias_f32, (float *)dev_priors_out_f32,
+                       (const unsigned short *)dev_labels, (const int *)dev_counts);
     if (dev_value_out_f32)
         hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
                            (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,

@@ -55,12 +55,26 @@ __device__ __forceinline__ void split_act(const float *row, bool valid, int k, h
 // bounds the launch (256 workgroups x 1 MiB at ~10 TB/s): NBLK = 2 halves that traffic for large
 // batches; NBLK = 1 keeps twice the workgroups for small ones.  Softmax statistics meet in LDS in a
 // fixed order (no atomics: reproducible).
-template <int NBLK>
+//
+// LEGAL: the search kernels only ever read the policy at the labels of a position's legal moves
+// (<= 218 of 1968).  Given that list (labels[board][256] in legal order, counts[board]) the kernel
+// parks the exponentials of its 16 boards in LDS (128 KiB) and writes priors[board][j] =
+// softmax[labels[board][j]] -- 4 x count bytes per board instead of 7 872, and the consumers read a
+// contiguous row instead of gathering 4-byte words from a 7.9-KB one.  Same values, bit for bit
+// (the same exp x (1 / sum) product).
+constexpr int LEGAL_STRIDE = 256;                        // priors / labels per board (= CRL_MAX_MOVES)
+constexpr int E_STRIDE = N_LABELS_PAD + 4;               // LDS row of a board: 16 rows start on 16 different bank quads
+constexpr int LEGAL_LDS_BYTES = 16 * E_STRIDE * 4;
+
+template <int NBLK, bool LEGAL = false>
 __global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict__ act, int n_boards,
                                                         const unsigned char *__restrict__ wp,   // packed fp16
                                                         const float *__restrict__ bias,          // [2048], pad = -1e30
-                                                        float *__restrict__ policy)
+                                                        float *__restrict__ policy,              // LEGAL: priors[n][256]
+                                                        const unsigned short *__restrict__ labels = nullptr,
+                                                        const int *__restrict__ counts = nullptr)
 {
+    static_assert(!LEGAL || NBLK == 1, "the legal-move gather handles one 16-board block");
     __shared__ float s_max[NBLK][8][16], s_sum[NBLK][8][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -157,7 +171,29 @@ __global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict_
 #pragma unroll
         for (int w = 1; w < 8; w++) tot += s_sum[nb][w][r];
         const float inv = 1.0f / tot;
-        if (valid[nb]) {
+        if constexpr (LEGAL) {
+            extern __shared__ __attribute__((aligned(16))) float s_e[];      // [16][E_STRIDE] + inv[16]
+#pragma unroll
+            for (int jt = 0; jt < 16; jt++)
+                *reinterpret_cast<f32x4h *>(s_e + r * E_STRIDE + wave * 256 + jt * 16 + 4 * q) = acc[nb][jt];
+            __syncthreads();
+            const int b = tid >> 5, l = tid & 31;          // 32 threads per board
+            const int gb = blockIdx.x * 16 + b;
+            if (gb < n_boards) {
+                // every lane of this half-wave needs board b's normaliser: lanes (r = b, q = 0) of
+                // any wave hold it; recomputing it from s_sum is 8 LDS reads and the same bits
+                float tb = s_sum[0][0][b];
+#pragma unroll
+                for (int w = 1; w < 8; w++) tb += s_sum[0][w][b];
+                const float inv_b = 1.0f / tb;
+                int cnt = counts[gb];
+                cnt = cnt < 0 ? 0 : (cnt > LEGAL_STRIDE ? LEGAL_STRIDE : cnt);
+                for (int j = l; j < cnt; j += 32) {
+                    const int lab = labels[(size_t)gb * LEGAL_STRIDE + j] & (N_LABELS_PAD - 1);
+                    policy[(size_t)gb * LEGAL_STRIDE + j] = s_e[b * E_STRIDE + lab] * inv_b;
+                }
+            }
+        } else if (valid[nb]) {
             float *out = policy + (size_t)board[nb] * N_LABELS + wave * 256 + 4 * q;
 #pragma unroll
             for (int jt = 0; jt < 16; jt++) {

@@ -185,29 +185,52 @@ __device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, con
     }
 }
 
+// legal = false: pol is a full policy[row][1968], gathered at the labels of the node's moves;
+// legal = true: pol is priors[row][MAX_MOVES], entry j for the node's legal move j (the evaluator
+// gathered them from the label list the search kernel that created the position wrote)
 __device__ inline void gather_priors(const Dev &d, int row, size_t eb, int edge0, int n,
-                                     const float *pol, int lane)
+                                     const float *pol, int lane, bool legal)
 {
     for (int j = lane; j < n; j += 64) {
         size_t e = eb + edge0 + j;
+        if (legal) {
+            d.edge[e].prior = pol[(size_t)row * MAX_MOVES + j];
+            continue;
+        }
         int lab = label_of(d, d.edge[e].move);
         if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
         d.edge[e].prior = pol[(size_t)row * N_LABELS + lab];
     }
 }
 
+// labels of the n moves in mv -> lab[row][0..n), count[row] = n (the evaluator's gather list)
+__device__ inline void write_labels(const Dev &d, int row, const u16 *mv, int n, u16 *lab, int32_t *count, int lane)
+{
+    for (int i = lane; i < n; i += 64) {
+        int l = label_of(d, mv[i]);
+        if (l >= N_LABELS) { dev_error(d, DERR_LABEL); l = 0; }
+        lab[(size_t)row * MAX_MOVES + i] = (u16)l;
+    }
+    if (lane == 0) count[row] = n;
+}
+
 // index of the first maximum of policy[label(m)] over the n moves in mv (np.argmax)
 __device__ inline int argmax_policy(const Dev &d, int row, const u16 *mv, int n, const float *pol,
-                                    int lane)
+                                    int lane, bool legal)
 {
     float best = -__builtin_inff();
     int bi = 0x7FFFFFFF;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i < n) {
-            int lab = label_of(d, mv[i]);
-            if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
-            float p = pol[(size_t)row * N_LABELS + lab];
+            float p;
+            if (legal) {
+                p = pol[(size_t)row * MAX_MOVES + i];
+            } else {
+                int lab = label_of(d, mv[i]);
+                if (lab >= N_LABELS) { dev_error(d, DERR_LABEL); lab = 0; }
+                p = pol[(size_t)row * N_LABELS + lab];
+            }
             if (p > best || bi == 0x7FFFFFFF) { best = p; bi = i; }
         }
     }
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(64) void k_greedy(Dev d, const float *pol, const ui
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
     if (mi.n == 0) return;                    // legal[argmax([])] would raise; game is over
-    const int bi = argmax_policy(d, r, s.mv, mi.n, pol, lane);
+    const int bi = argmax_policy(d, r, s.mv, mi.n, pol, lane, false);    // always a full policy
     const u32 mv = s.mv[bi];
     __syncthreads();
     if (lane == 0) moves_out[r] = (u16)mv;
@@ -443,7 +466,7 @@ __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.game[g].root_dead) return;
     NodeMeta m = d.node[(size_t)g * d.N].meta;
-    gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane);
+    gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane, false);   // the root's policy is always full
     if (lane == 0) d.counters[(size_t)g * CNT_N + CNT_EVALS] += 1;
 }
 
@@ -463,7 +486,7 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
         v = (double)m.result;                          // state.get_result() (mctree.py:268)
     } else {
         v = (double)val2[row];                           // python float of the f32 value head
-        gather_priors(d, row, eb, m.edge0, m.nmoves, pol2, lane);
+        gather_priors(d, row, eb, m.edge0, m.nmoves, pol2, lane, d.policy_fmt != 0);
         evals = 1;                                     // policy/value(S2)
     }
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
@@ -498,6 +521,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
 {
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    if (lane == 0) d.lab_n1[r] = 0;                     // no policy(S1) wanted unless a reply is needed
     if (d.game[g].root_dead) return;
     backup_pending(d, g, r, lane, pol2, val2);
 
@@ -548,6 +572,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
                 }
             } else {
                 for (int i = lane; i < e.n; i += 64) d.s1_moves[(size_t)g * MAX_MOVES + i] = s.mv[i];
+                if (d.policy_fmt) write_labels(d, r, s.mv, e.n, d.lab_s1, d.lab_n1, lane);
                 if (lane == 0) {
                     d.edge[eb + edge].child = (u16)c;
                     d.game[g].s1_n = e.n;
@@ -604,19 +629,21 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
 {
     __shared__ WaveLds s;
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
+    if (lane == 0) d.lab_n2[r] = 0;                     // no policy(S2) wanted unless a new node gets priors
     if (d.game[g].root_dead || d.game[g].leaf_kind != LEAF_NEW_REPLY) return;
     const size_t nb = (size_t)g * d.N, eb = (size_t)g * d.ECAP;
     const int c = uni(d.game[g].leaf_node), level = uni(d.game[g].path_len), n1 = uni(d.game[g].s1_n), p = uni(d.game[g].ply);
     Board s1 = d.node[nb + c].s1;
     // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
     const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
-    const int bi = argmax_policy(d, r, mv1, n1, pol1, lane);
+    const int bi = argmax_policy(d, r, mv1, n1, pol1, lane, d.policy_fmt != 0);
     const u32 reply = mv1[bi];
     Board s2 = apply_move(s1, reply);
     PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);
     const int edge0 = uni(d.game[g].edge_top);
     if (edge0 + e.n > d.ECAP) { dev_error(d, DERR_EDGE_POOL); return; }
     init_edges(d, eb, edge0, e.n, s.mv, lane);
+    if (d.policy_fmt && e.result == RESULT_NONE) write_labels(d, r, s.mv, e.n, d.lab_s2, d.lab_n2, lane);
     if (lane == 0) {
         NodeMeta m = d.node[nb + c].meta;
         m.edge0 = edge0; m.nmoves = (u16)e.n; m.nexp = 0; m.result = (int8_t)e.result; m.has_s2 = 1;

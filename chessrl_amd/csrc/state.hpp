@@ -95,6 +95,8 @@ struct Dev {
     int g0;                            // first slot of the active window (I/O rows are window-relative)
     u32 flags;
     int plane_fmt;                     // 0: encoders write fp16 NHWC planes, 1: 128 bit planes per position
+    int policy_fmt;                    // 0: evaluators hand back policy[row][1968]; 1: priors[row][256] of the
+                                       //    legal moves the search kernels listed in lab_s1 / lab_s2
     // games
     GameRow *game;
     Board *cur;
@@ -108,6 +110,10 @@ struct Dev {
     int32_t *path_edge;
     u16 *path_node;
     u16 *s1_moves;
+    // policy labels of the legal moves of the position each tower call evaluates, in legal order
+    // (rows are window-relative like every evaluator buffer): S1 by k_select_expand, S2 by k_reply
+    u16 *lab_s1, *lab_s2;              // [G][MAX_MOVES]
+    int32_t *lab_n1, *lab_n2;          // [G]; 0 when the row needs no policy this step
     // misc
     const u16 *lut;                    // [5][4096] move -> label index (0xFFFF = none)
     unsigned long long *counters;      // [G][CNT_N]

@@ -84,7 +84,7 @@ class LockstepEngine(object):
     """
 
     def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
-                 numpy_promotion="nep50", use_graph=True, bitplanes=None):
+                 numpy_promotion="nep50", use_graph=True, bitplanes=None, legal_priors=None):
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
         if numpy_promotion not in ("nep50", "legacy"):
@@ -112,7 +112,24 @@ class LockstepEngine(object):
         self.pol_s1 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.pol_s2 = torch.zeros((G, _lib.N_LABELS), dtype=torch.float32, device=self.dev)
         self.val_s2 = torch.zeros((G,), dtype=torch.float32, device=self.dev)
-        self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2)
+        # An evaluator with ``accepts_legal_labels`` (the HIP heads) is told which labels the search
+        # will read -- the legal moves of S1 / S2, listed by the kernel that generated them -- and
+        # writes only those probabilities: priors [G,256] instead of policy [G,1968] per call
+        # (CRL_POLICY_LEGAL).  Root priors and greedy openings still use the full vectors.
+        if legal_priors is None:
+            legal_priors = bool(getattr(evaluator, "accepts_legal_labels", False))
+        self.legal_priors = legal_priors
+        self.pri_s1 = self.pri_s2 = None
+        if legal_priors:
+            self.ctx.set_policy_format(True)
+            self.pri_s1 = torch.zeros((G, _lib.MAX_MOVES), dtype=torch.float32, device=self.dev)
+            self.pri_s2 = torch.zeros((G, _lib.MAX_MOVES), dtype=torch.float32, device=self.dev)
+            self._lab_s1 = self.ctx.eval_labels(0)
+            self._lab_s2 = self.ctx.eval_labels(1)
+        else:
+            self.pri_s1, self.pri_s2 = self.pol_s1, self.pol_s2
+        self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
+                      self.pri_s1, self.pri_s2)
         self.use_graph = use_graph
         self._graph = None
         self._bind_stream()
@@ -133,7 +150,8 @@ class LockstepEngine(object):
             raise ValueError("shrink: n must be a multiple of 4 within the engine's capacity")
         self.ctx.set_window(0, n)
         self.G = n
-        self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2 = (t[:n] for t in self._full)
+        (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
+         self.pri_s1, self.pri_s2) = (t[:n] for t in self._full)
         self._graph = None
 
     def _eval_into(self, planes, pol_out, val_out):
@@ -146,12 +164,30 @@ class LockstepEngine(object):
         if val_out is not None:
             val_out.copy_(val)
 
+    # the four phases of one simulation step (bench.py times them one by one)
+    def phase_select_expand(self):
+        self.ctx.sim_select_expand(self.pri_s2.data_ptr(), self.val_s2.data_ptr(), self.planes_s1.data_ptr())
+
+    def phase_tower_s1(self):
+        if self.legal_priors:
+            self.evaluator.forward_legal_into(self.planes_s1, self._lab_s1[0], self._lab_s1[1], self.pri_s1, None)
+        else:
+            self._eval_into(self.planes_s1, self.pol_s1, None)
+
+    def phase_reply(self):
+        self.ctx.sim_reply(self.pri_s1.data_ptr(), self.planes_s2.data_ptr())
+
+    def phase_tower_s2(self):
+        if self.legal_priors:
+            self.evaluator.forward_legal_into(self.planes_s2, self._lab_s2[0], self._lab_s2[1], self.pri_s2, self.val_s2)
+        else:
+            self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
+
     def _step_body(self):
-        c = self.ctx
-        c.sim_select_expand(self.pol_s2.data_ptr(), self.val_s2.data_ptr(), self.planes_s1.data_ptr())
-        self._eval_into(self.planes_s1, self.pol_s1, None)
-        c.sim_reply(self.pol_s1.data_ptr(), self.planes_s2.data_ptr())
-        self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
+        self.phase_select_expand()
+        self.phase_tower_s1()
+        self.phase_reply()
+        self.phase_tower_s2()
 
     def _capture(self):
         # warm the evaluator (library handles, autotuning) outside of capture
@@ -193,7 +229,7 @@ class LockstepEngine(object):
         self.search_begin()
         for _ in range(n_sims):
             self.step()
-        self.ctx.sim_backup(self.pol_s2.data_ptr(), self.val_s2.data_ptr())
+        self.ctx.sim_backup(self.pri_s2.data_ptr(), self.val_s2.data_ptr())
 
     def root_children(self):
         return self.ctx.root_children()

@@ -316,6 +316,31 @@ class ChessModel(object):
             raise _lib.HipLibraryError("crl_heads_forward failed (%d)" % rc)
         return p, v
 
+    @property
+    def accepts_legal_labels(self):
+        """The HIP heads can write just the probabilities of a position's legal moves
+        (crl_heads_forward_legal): the engine then never materialises the 1968-vectors."""
+        return bool(self.fused)
+
+    @torch.no_grad()
+    def forward_legal_into(self, planes, labels_ptr, counts_ptr, priors_out, val_out):
+        """Evaluate and write, per board, the policy at the labels listed in the device arrays
+        ``labels_ptr`` (uint16 [B,256]) / ``counts_ptr`` (int32 [B]) into ``priors_out`` (fp32
+        [B,256]) and the value into ``val_out`` (fp32 [B], or None: S1 evaluations need no value)."""
+        import ctypes
+        from . import _lib
+        if not self.fused:
+            raise _lib.HipLibraryError("forward_legal_into needs the fused HIP tower")
+        _, hp = self._run_fused(planes)
+        vp = ctypes.c_void_p
+        rc = _lib.lib().crl_heads_forward_legal(
+            vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), hp.shape[0],
+            vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
+            vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr), vp(counts_ptr),
+            vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None))
+        if rc != 0:
+            raise _lib.HipLibraryError("crl_heads_forward_legal failed (%d)" % rc)
+
     @torch.no_grad()
     def forward_into(self, planes, pol_out, val_out):
         """Evaluate and write policy [B,1968] / value [B] into existing fp32 tensors."""

@@ -131,7 +131,7 @@ class SelfPlayRunner(object):
         """Last backprop, compute_policy + argmax on the host, the two pushes, harvest of
         finished games and refill of their slots."""
         eng = self.engine
-        eng.ctx.sim_backup(eng.pol_s2.data_ptr(), eng.val_s2.data_ptr())
+        eng.ctx.sim_backup(eng.pri_s2.data_ptr(), eng.val_s2.data_ptr())
         rc = eng.ctx.root_children(("nchild", "visits", "root_visits"))
         _, plies, _ = eng.ctx.records(with_moves=False)
         nchild = np.where(self.game_id >= 0, rc["nchild"], 0)

@@ -82,6 +82,21 @@ int  crl_set_window(crl_ctx *ctx, int first, int count);
 #define CRL_PLANES_F16  0
 #define CRL_PLANES_BITS 1
 int  crl_set_plane_format(crl_ctx *ctx, int format);
+/* What the evaluator hands back to crl_sim_select_expand / crl_sim_reply / crl_sim_backup as
+ * "policy" (mctree.py:298-303 _update_prior and agentdistributed.py:80-82 read the 1968-vector only
+ * at the labels of the position's legal moves):
+ * CRL_POLICY_FULL (default) = dev_policy rows are float32 [1968], the kernels gather at the labels;
+ * CRL_POLICY_LEGAL = dev_policy rows are float32 [CRL_MAX_MOVES]: entry j is the probability of the
+ * position's legal move j (crl_legal_moves order).  The search kernels then publish, for the position
+ * each tower call evaluates, the labels of its legal moves: crl_eval_labels(ctx, 0, ...) after
+ * crl_sim_select_expand (S1), crl_eval_labels(ctx, 1, ...) after crl_sim_reply (S2): device pointers
+ * to uint16 [count][CRL_MAX_MOVES] and int32 [count] (0 = this row needs no policy in this step),
+ * rows window-relative, valid for the life of the context.  crl_heads_forward_legal consumes them.
+ * crl_search_root_priors and crl_greedy_moves always take full policies. */
+#define CRL_POLICY_FULL  0
+#define CRL_POLICY_LEGAL 1
+int  crl_set_policy_format(crl_ctx *ctx, int format);
+int  crl_eval_labels(crl_ctx *ctx, int which, const uint16_t **dev_labels, const int32_t **dev_counts);
 int  crl_max_games(crl_ctx *ctx);
 int  crl_max_sims(crl_ctx *ctx);
 
@@ -212,6 +227,16 @@ int  crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boa
                        const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
                        const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
                        const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32);
+
+/* crl_heads_forward writing only what the search reads: dev_priors_out_f32 [n_boards][CRL_MAX_MOVES],
+ * entry j of row b = softmax(...)[dev_labels[b][j]] for j < dev_counts[b] (the rest of the row is left
+ * untouched) -- 4 x count bytes per board instead of 7 872, bit-identical values.  dev_labels uint16
+ * [n_boards][CRL_MAX_MOVES], dev_counts int32 [n_boards] (crl_eval_labels).  Stateless. */
+int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                             const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                             const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                             const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
+                             const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32);
 
 /* Batches of at most 512 boards (256 at 256 filters) give at most half of the 256 CUs a
  * workgroup; they run the same kernels with half the boards per workgroup and twice the

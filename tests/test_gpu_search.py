@@ -445,6 +445,77 @@ def test_fused_trunk_from_bitplanes_is_bit_identical(filters, n_boards):
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_boards", [5, 64, 1000])
+def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards):
+    """crl_heads_forward_legal: priors[b][j] == policy[b][labels[b][j]] bit for bit for j < counts[b]
+    (0, 1, typical and the maximum 218 labels per board), nothing written past the count."""
+    import ctypes
+    from chessrl_amd import _lib
+    from chessrl_amd.model import ChessModel
+    model = ChessModel(weights=tower_oracle.init_weights(2, 64, seed=22, randomize_bn=True))
+    rng = np.random.default_rng(100 + n_boards)
+    hp = torch.from_numpy(np.abs(rng.normal(0, 1.5, (n_boards, 192))).astype(np.float32)).cuda()
+    counts = rng.integers(0, 60, n_boards).astype(np.int32)
+    counts[:4] = [0, 1, 218, 35][:min(4, n_boards)]
+    labels = np.zeros((n_boards, 256), np.uint16)
+    for b in range(n_boards):
+        labels[b, :counts[b]] = rng.permutation(1968)[:counts[b]]
+    lab_d, cnt_d = torch.from_numpy(labels.view(np.int16)).cuda(), torch.from_numpy(counts).cuda()
+    vp = ctypes.c_void_p
+    args = (vp(torch.cuda.current_stream().cuda_stream), vp(hp.data_ptr()), n_boards,
+            vp(model._pol_wp.data_ptr()), vp(model._pol_bias.data_ptr()), vp(model._val_w1p.data_ptr()),
+            vp(model._val_b1.data_ptr()), vp(model._val_w2.data_ptr()))
+    pol = torch.zeros((n_boards, 1968), device="cuda")
+    val = torch.zeros((n_boards,), device="cuda")
+    assert _lib.lib().crl_heads_forward(*args, vp(pol.data_ptr()), vp(val.data_ptr())) == 0
+    pri = torch.full((n_boards + 2, 256), -7.0, device="cuda")
+    val2 = torch.full((n_boards + 2,), -7.0, device="cuda")
+    assert _lib.lib().crl_heads_forward_legal(*args, vp(lab_d.data_ptr()), vp(cnt_d.data_ptr()),
+                                              vp(pri.data_ptr()), vp(val2.data_ptr())) == 0
+    torch.cuda.synchronize()
+    pol, pri = pol.cpu().numpy(), pri.cpu().numpy()
+    for b in range(n_boards):
+        n = counts[b]
+        assert np.array_equal(pri[b, :n].view(np.uint32), pol[b, labels[b, :n]].view(np.uint32)), b
+        assert (pri[b, n:] == -7.0).all()
+    assert (pri[n_boards:] == -7.0).all()
+    assert torch.equal(val2[:n_boards], val) and (val2[n_boards:] == -7.0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sims,graph", [(40, False), (130, True)])
+def test_search_with_legal_priors_is_identical_to_search_with_full_policies(sims, graph):
+    """CRL_POLICY_LEGAL (the heads write only the legal moves' probabilities, the search kernels
+    publish the label lists) against CRL_POLICY_FULL on the same games: same trees, bit for bit,
+    through replies, terminal children, finished roots, and a second move after advance."""
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    model = ChessModel(blocks=2, filters=64, seed=3)
+    games = random_prefix_games(24, 70, seed=29)
+    out = []
+    for legal in (False, True):
+        eng = LockstepEngine(model, n_games=24, max_sims=sims, legal_priors=legal, use_graph=graph)
+        assert eng.legal_priors == legal
+        eng.load_moves([move_ids(g) for g in games])
+        eng.search(sims)
+        first = eng.root_children()
+        chosen = np.where(first["nchild"] > 0, np.maximum(first["visits"].argmax(1), 0), -1).astype(np.int32)
+        bm, am = eng.advance(chosen)
+        eng.search(sims)
+        out.append((first, bm, am, eng.root_children(), eng.ctx.counters()))
+        eng.close()
+    (a1, abm, aam, a2, ac), (b1, bbm, bam, b2, bc) = out
+    for a, b in ((a1, b1), (a2, b2)):
+        assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
+        assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+        assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
+        assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
+    assert np.array_equal(abm, bbm) and np.array_equal(aam, bam)
+    assert {k: int(v) for k, v in ac.items()} == {k: int(v) for k, v in bc.items()}
+    assert LockstepEngine(model, n_games=4, max_sims=2).legal_priors      # the default for the HIP heads
+
+
 def test_search_with_the_real_tower_is_identical_in_both_plane_formats():
     from chessrl_amd.engine import LockstepEngine
     from chessrl_amd.model import ChessModel

@@ -36,17 +36,21 @@ for tag, shape in shapes.items():
                        "write_size_kb": round(w[k][0], 1),
                        "source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc, tools/trunk_once.py, %d launches)" % f[k][1]})
         summary[short + " @ " + shape] = {"FETCH_SIZE_KB": f[k][0], "WRITE_SIZE_KB": w[k][0]}
-tf = per_kernel(os.path.join(SRC, "tree_FETCH_SIZE.csv"), last=50)
-tw = per_kernel(os.path.join(SRC, "tree_WRITE_SIZE.csv"), last=50)
-tree = {k.split("::")[-1]: {"FETCH_SIZE_KB": tf[k][0], "WRITE_SIZE_KB": tw[k][0], "launches": tf[k][1]}
-        for k in tf if "k_select_expand" in k or "k_reply" in k}
-shape_file = os.path.join(SRC, "tree_shape.json")
-tree_shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {}
-summary["search kernels, 4096 games, bit planes (mean of the last 50 launches)"] = dict(tree, tree=tree_shape)
-passes.append({"kernel": "k_select_expand + k_reply", "shape": "4096 games, bit planes",
-               "fetch_size_kb": round(sum(v["FETCH_SIZE_KB"] for v in tree.values()), 1),
-               "write_size_kb": round(sum(v["WRITE_SIZE_KB"] for v in tree.values()), 1),
-               "source": "profiles/r02/pmc_summary.json (tools/tree_once.py 4096 400 1, last 50 launches; %s)" % json.dumps(tree_shape)})
+for tag, fmt in (("tree", "legal priors"), ("treefull", "full policies")):
+    if not os.path.exists(os.path.join(SRC, tag + "_FETCH_SIZE.csv")):
+        continue
+    tf = per_kernel(os.path.join(SRC, tag + "_FETCH_SIZE.csv"), last=50)
+    tw = per_kernel(os.path.join(SRC, tag + "_WRITE_SIZE.csv"), last=50)
+    tree = {k.split("::")[-1]: {"FETCH_SIZE_KB": tf[k][0], "WRITE_SIZE_KB": tw[k][0], "launches": tf[k][1]}
+            for k in tf if "k_select_expand" in k or "k_reply" in k}
+    shape_file = os.path.join(SRC, tag + "_shape.json")
+    tree_shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {}
+    summary["search kernels, 4096 games, bit planes, %s (mean of the last 50 launches)" % fmt] = dict(tree, tree=tree_shape)
+    passes.append({"kernel": "k_select_expand + k_reply", "shape": "4096 games, bit planes, %s" % fmt,
+                   "fetch_size_kb": round(sum(v["FETCH_SIZE_KB"] for v in tree.values()), 1),
+                   "write_size_kb": round(sum(v["WRITE_SIZE_KB"] for v in tree.values()), 1),
+                   "source": "profiles/r02/pmc_summary.json (tools/tree_once.py 4096 400 1, %s, last 50 launches; %s)"
+                             % (fmt, json.dumps(tree_shape))})
 json.dump(summary, open(os.path.join(DST, "pmc_summary.json"), "w"), indent=1)
 table = {"what": "HBM-side traffic per launch from rocprofv3 PMC passes (one counter per pass; FETCH_SIZE and "
                  "WRITE_SIZE in KB as rocprofv3 reports them; bench.py applies the gfx950 x2 wide-read correction to "

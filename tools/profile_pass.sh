@@ -17,8 +17,10 @@ pmc trunk256 FETCH_SIZE python3 $R/tools/trunk_once.py 20 256 4096
 pmc trunk256 WRITE_SIZE python3 $R/tools/trunk_once.py 20 256 4096
 pmc trunk64 FETCH_SIZE python3 $R/tools/trunk_once.py 6 64 512
 pmc trunk64 WRITE_SIZE python3 $R/tools/trunk_once.py 6 64 512
-pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json
-pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1
+pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 1
+pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
+pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0
+pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
 for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
