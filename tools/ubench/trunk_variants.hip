@@ -170,6 +170,8 @@ int main(int argc, char **argv)
         typedef Geo<64, 4> G4; typedef Geo<64, 2> G2;
         run("k_trunk_gen<64,4,1> production", k_trunk_gen<64, 4, 1>, G4::LDS_BYTES, 4, 64, 6, boards, reps, b, ref, nullptr);
         run("k_trunk_x16<64,4,1> 16x16x32", k_trunk_x16<64, 4, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
+        stamps<64, 4>(b, 6, boards);
+        stamps<64, 2>(b, 6, 512);
         run("k_trunk_x16<64,4,1,1> alt issuer", k_trunk_x16<64, 4, 1, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
         run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1>, G2::LDS_BYTES, 2, 64, 6, 512, reps, b, ref, nullptr);
         run("k_trunk_x16<64,2,1> 16x16x32 512", k_trunk_x16<64, 2, 1>, Geo16<64, 2>::LDS_BYTES, 2, 64, 6, 512, reps, b, out, &ref);
