@@ -600,11 +600,15 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
     // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count; 128 and 256
     // filters with one barrier per two weight tiles over a five-slot ring (PAIR)
+    // 64 filters at four boards per workgroup: taps in groups of three over a nine-slot ring (GROUP);
+    // at two boards per workgroup (batches <= 512) the plain ring of four measured faster
 #define CRL_X16(F_, NB_)                                                                        \
     do {                                                                                         \
         constexpr int pair = (F_ == 64) ? 0 : 1;                                                 \
-        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1, 0, pair> : crl_tower::k_trunk_x16<F_, NB_, 0, 0, pair>; \
-        lds_bytes = crl_tower::Geo16<F_, NB_>::lds_bytes(pair ? 5 : crl_tower::PIPE_RING);       \
+        constexpr int group = (F_ == 64 && NB_ == 4) ? 1 : 0;                                    \
+        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1, 0, pair, group>                         \
+                    : crl_tower::k_trunk_x16<F_, NB_, 0, 0, pair, group>;                        \
+        lds_bytes = crl_tower::Geo16<F_, NB_>::lds_bytes(group ? 9 : (pair ? 5 : crl_tower::PIPE_RING)); \
         boards_per_wg = NB_;                                                                     \
     } while (0)
     if (filters == 256) {

@@ -138,6 +138,17 @@ __device__ inline void stage_bias_x16(const float *bias, lds_byte *lds, int conv
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+template <int N> __device__ __forceinline__ void wait_vmcnt_n()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkm_n()
+{
+    static_assert(N >= 0 && N < 16, "lgkmcnt immediate");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_lgkm()
 {
     static_assert(N >= 0 && N <= 8 && N != 7, "lgkmcnt immediate");
@@ -158,7 +169,16 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 // PAIR = 1 (128 and 256 filters): ONE barrier per TWO weight tiles over a ring of five slots.  The
 // sync sits at the start of the last sub-step of every odd tile t: tiles t+1, t+2 (moved at the
 // previous sync) are published, tiles t+3, t+4 go into the slots of the dead tiles t-2, t-1.
-template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0>
+// GROUP = 1 (64 filters).  There a wave tile is 2x2 / 2x4 blocks: a sub-step is 4 / 8 MFMAs per
+// wave and a weight tile (one tap, 8 KiB) lasts 256 / 512 cycles.  The half-sub-step pipeline then
+// leaves 2-4 MFMAs between a fragment read and its use (LDS latency is 10x that) and the ring of
+// four looks one or two taps ahead of the L2 latency of the weight DMA: the loops ran at 30-45 % of
+// their MFMA pace.  GROUP runs the taps in groups of three (one weight tile each, the stem's 128
+// planes as two virtual taps of 64): ONE barrier per group, a weight ring of 3 (4 at two boards per
+// workgroup) groups, so a tile is requested two (three) groups before it is read, and inside a
+// group the six sub-steps run back to back with their fragments fetched TWO sub-steps ahead into
+// three register buffers, across tap boundaries (not across layers: those activations do not exist yet).
+template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0, int GROUP = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -187,12 +207,22 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
     static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2)), "pair publishing: even tile counts per layer");
-    static_assert(G::lds_bytes(PAIR ? 5 : PIPE_RING) <= 160 * 1024, "LDS budget");
+    constexpr int GK = 3;                               // GROUP: taps (= tiles) per barrier
+    constexpr int GRG = NB == 2 ? 4 : 3;                // GROUP: groups in the weight ring
+    constexpr int GR = GK * GRG;                        // GROUP: ring slots
+    static_assert(G::lds_bytes(GROUP ? GR : (PAIR ? 5 : PIPE_RING)) <= 160 * 1024, "LDS budget");
+    static_assert(!GROUP || (F == 64 && !PAIR && (ALT == 0 || ALT == 2) && G::SPT == 2 && G::GL == 1 &&
+                             2 * (PT + CT) < 16), "group pipeline: 64 filters");
     stage_bias_x16<G, F>(bias, lds, 0, lane, wave_u);   // oldest transfer: landed when tile 0 has
-    stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u, PAIR ? 0 : -1);
-    stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u, PAIR ? 1 : -1);
-    stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u, PAIR ? 2 : -1);
-    if constexpr (PAIR) stage_wtile_x16<G, ALT>(wts, lds, 3, tid, wave_u, 3);
+    if constexpr (GROUP) {
+#pragma unroll
+        for (int k = 0; k < GK * (GRG - 1); k++) stage_wtile_x16<G, 0>(wts, lds, k, tid, wave_u, k);   // groups 0 .. GRG-2
+    } else {
+        stage_wtile_x16<G, ALT>(wts, lds, 0, tid, wave_u, PAIR ? 0 : -1);
+        stage_wtile_x16<G, ALT>(wts, lds, 1, tid, wave_u, PAIR ? 1 : -1);
+        stage_wtile_x16<G, ALT>(wts, lds, 2, tid, wave_u, PAIR ? 2 : -1);
+        if constexpr (PAIR) stage_wtile_x16<G, ALT>(wts, lds, 3, tid, wave_u, 3);
+    }
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
         if constexpr (BITS) {
@@ -214,7 +244,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     }
     // tile 0 landed (tiles 1,2 may be in flight).  ALT: waves 0-3 moved tiles 0 and 2, waves 4-7 tile 1.
     // PAIR: tiles 0 AND 1 landed (1 is first read before the first sync), 2 and 3 in flight
-    if constexpr (ALT == 1) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
+    if constexpr (GROUP) wait_vmcnt_n<GK * (GRG - 2)>();              // group 0 landed, groups 1 .. GRG-2 in flight
+    else if constexpr (ALT == 1) { if (wave_u < 4) wait_vmcnt<2 * G::GL>(); }
     else wait_vmcnt<2 * G::GL>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -402,7 +433,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         // A spatial tap with more than 128 input channels runs as Cin/128 "virtual taps" of 128
         // channels each (same neighbour rows, channel offset 256 bytes further): every virtual tap
         // is NS = 4 sub-steps, one unrolled body for the stem and the 128- and 256-filter layers.
-        const int hshift = (conv != 0 && F == 256) ? 1 : 0;
+        // (GROUP: virtual taps of 64 channels, so it is the stem's 128 planes that split in two)
+        const int hshift = GROUP ? (conv == 0 ? 1 : 0) : ((conv != 0 && F == 256) ? 1 : 0);
+        constexpr int chstep = GROUP ? 128 : 256;       // bytes between the channel halves of a spatial tap
         const int nv = 9 << hshift;
         // Activation row address of block pt for virtual tap v: the lane's own row shifted by
         // (8 dy + dx) rows when that neighbour is on the board, else the zero row whose index has
@@ -412,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             const int tap = v >> hshift;
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int shift = 8 * dy + dx;
-            const int choff = (v & ((1 << hshift) - 1)) * 256;
+            const int choff = (v & ((1 << hshift) - 1)) * chstep;
             const int zrow = zero_q + ((r + shift) & 15) * G::AROW + choff;
             const int inb = base0 + shift * G::AROW + choff;
             // on-board tests as wave masks in SGPRs (computed once per kernel): per block only a
@@ -425,6 +458,83 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst[pt]) : "v"(zrow), "v"(row), "s"(m));
             }
         };
+        if constexpr (GROUP) {
+            constexpr int FR = PT + CT;                 // fragment reads of one sub-step
+            half8 fx[3][PT], fw[3][CT];                 // sub-step i lives in buffer i % 3
+            const int n_groups = n_tiles / GK;
+            for (int g0 = 0; g0 < nv; g0 += GK) {       // virtual taps g0 .. g0+2 = tiles t .. t+2
+                const bool more = g0 + GK < nv;         // the layer has another group
+                int rows[GK + 1][PT], wb[GK + 1];
+#pragma unroll
+                for (int k = 0; k <= GK; k++) {
+                    vtap_rows(g0 + k < nv ? g0 + k : 0, rows[k]);
+                    int slot = slot_tap + k;
+                    slot = slot >= GR ? slot - GR : slot;
+                    wb[k] = w0 + slot * G::TILE_BYTES;
+                }
+                // sub-step j of the group (j >= 6: of the next group) -> buffer j % 3
+                auto fetch = [&](auto JC) {
+                    constexpr int j = decltype(JC)::value, b = j % 3, k = j / 2, pl = j % 2;
+#pragma unroll
+                    for (int pt = 0; pt < PT; pt++) fx[b][pt] = lds_read16_asm<pl * 64>(rows[k][pt]);
+                    static_for<0, CT>([&](auto CC) {
+                        constexpr int ct = decltype(CC)::value;
+                        fw[b][ct] = lds_read16_asm<ct * 1024 + pl * G::WPLANE>(wb[k]);
+                    });
+                };
+                if (g0 == 0) {                          // cold start of a layer
+                    fetch(std::integral_constant<int, 0>{});
+                    fetch(std::integral_constant<int, 1>{});
+                }
+                static_for<0, 2 * GK>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    if constexpr (i == 2 * GK - 2) {
+                        // ---- the group's sync, before the first fetch from the next group's tiles:
+                        // group tg+1 has landed everywhere, nobody reads group tg-1 any more -> its
+                        // slots take group tg + GRG - 1
+                        const int tg = t / GK;
+                        if (tg + 1 < n_groups) {
+                            unsigned long long s0 = 0, s1 = 0;
+                            if constexpr (STAMP) s0 = __builtin_amdgcn_s_memtime();
+                            if (tg + GRG - 2 < n_groups) wait_vmcnt_n<GK * (GRG - 3)>();   // younger groups stay in flight
+                            else wait_vmcnt_n<0>();
+                            if constexpr (STAMP) { s1 = __builtin_amdgcn_s_memtime(); t_vm += s1 - s0; }
+                            __builtin_amdgcn_s_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (STAMP) t_sb += __builtin_amdgcn_s_memtime() - s1;
+                            if (!bias_staged) {
+                                bias_staged = true;
+                                if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
+                            }
+                            if (tg + GRG - 1 < n_groups) {
+                                int slot = slot_tap - GK;                       // slots of group tg-1
+                                slot = slot < 0 ? slot + GR : slot;
+#pragma unroll
+                                for (int k = 0; k < GK; k++)
+                                    stage_wtile_x16<G, 0>(wts, lds, (tg + GRG - 1) * GK + k, tid, wave_u, slot + k);
+                            }
+                        }
+                    }
+                    // fetch sub-step i+2 (the last two reach into the next group of this layer)
+                    if constexpr (i + 2 < 2 * GK) fetch(std::integral_constant<int, i + 2>{});
+                    else if (more) fetch(std::integral_constant<int, i + 2>{});
+                    // sub-step i's fragments have landed: at most the younger fetches stay outstanding
+                    if constexpr (i + 2 < 2 * GK) wait_lgkm_n<2 * FR>();
+                    else if constexpr (i == 2 * GK - 2) { if (more) wait_lgkm_n<2 * FR>(); else wait_lgkm_n<FR>(); }
+                    else { if (more) wait_lgkm_n<2 * FR>(); else wait_lgkm_n<0>(); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ct++)
+                            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i % 3][ct], fx[i % 3][pt], acc[pt][ct], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                t += GK;
+                slot_tap += GK;
+                slot_tap = slot_tap >= GR ? slot_tap - GR : slot_tap;
+            }
+        } else {
         vtap_rows(0, ab[1]);
         for (int v = 0; v < nv; v++) {
 #pragma unroll
@@ -433,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, v == 0, v == nv - 1);
             else run_tap(std::integral_constant<int, 4>{}, v == 0, v == nv - 1);
             if constexpr (PAIR) slot_tap = slot_add(slot_tap, 4 / G::SPT);
+        }
         }
 
         // ---- epilogue ------------------------------------------------------------------------------

@@ -95,13 +95,13 @@ static Bufs make(int F, int blocks, int boards)
     return b;
 }
 
-template <int F, int NB, int PAIR = 0>
+template <int F, int NB, int PAIR = 0, int GROUP = 0>
 static void stamps(const Bufs &b, int blocks, int boards)
 {
     if (getenv("MATCH")) return;
     typedef Geo16<F, NB> G;
-    kern_t k = k_trunk_x16<F, NB, 1, 2, PAIR>;
-    const int lds = G::lds_bytes(PAIR ? 5 : 4);
+    kern_t k = k_trunk_x16<F, NB, 1, 2, PAIR, GROUP>;
+    const int lds = G::lds_bytes(GROUP ? (NB == 2 ? 12 : 9) : (PAIR ? 5 : 4));
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nwg = boards / NB;
     unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)nwg * 8 * 6 * 8));
@@ -118,7 +118,7 @@ static void stamps(const Bufs &b, int blocks, int boards)
     const int n = nwg * 8, convs = 1 + 2 * blocks;
     const double mf = (F == 64 ? (4.0 + 2.0 * blocks * 2) : F == 128 ? 4.0 * convs : (4.0 + 2.0 * blocks * 8)) * 9 * (G::PT * G::CT) * 16 * 2;
     printf("stamps x16<%d,%d%s>: per wave: main loops %.0f cycles (MFMA-paced minimum at 2 waves/SIMD %.0f), epilogues %.0f (%.0f per conv), "
-           "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, PAIR ? ", pair sync" : "", loop / n, mf, epi / n, epi / n / convs, tot / n,
+           "whole kernel %.0f; loop share %.3f epilogue share %.3f\n", F, NB, PAIR ? ", pair sync" : (GROUP ? ", groups of 3" : ""), loop / n, mf, epi / n, epi / n / convs, tot / n,
            loop / tot, epi / tot);
     printf("   epilogue phases per conv: wait at the first barrier %.0f, convert + LDS writes %.0f, second barrier %.0f cycles\n",
            ba / n / convs, wr / n / convs, (epi - ba - wr) / n / convs);
@@ -170,11 +170,15 @@ int main(int argc, char **argv)
         typedef Geo<64, 4> G4; typedef Geo<64, 2> G2;
         run("k_trunk_gen<64,4,1> production", k_trunk_gen<64, 4, 1>, G4::LDS_BYTES, 4, 64, 6, boards, reps, b, ref, nullptr);
         run("k_trunk_x16<64,4,1> 16x16x32", k_trunk_x16<64, 4, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
+        run("k_trunk_x16<64,4,1,0,0,1> groups of 3", k_trunk_x16<64, 4, 1, 0, 0, 1>, Geo16<64, 4>::lds_bytes(9), 4, 64, 6, boards, reps, b, out, &ref);
         stamps<64, 4>(b, 6, boards);
         stamps<64, 2>(b, 6, 512);
+        stamps<64, 4, 0, 1>(b, 6, boards);
+        stamps<64, 2, 0, 1>(b, 6, 512);
         run("k_trunk_x16<64,4,1,1> alt issuer", k_trunk_x16<64, 4, 1, 1>, Geo16<64, 4>::LDS_BYTES, 4, 64, 6, boards, reps, b, out, &ref);
         run("k_trunk_gen<64,2,1> production 512", k_trunk_gen<64, 2, 1>, G2::LDS_BYTES, 2, 64, 6, 512, reps, b, ref, nullptr);
         run("k_trunk_x16<64,2,1> 16x16x32 512", k_trunk_x16<64, 2, 1>, Geo16<64, 2>::LDS_BYTES, 2, 64, 6, 512, reps, b, out, &ref);
+        run("k_trunk_x16<64,2,1,0,0,1> groups of 3, 512", k_trunk_x16<64, 2, 1, 0, 0, 1>, Geo16<64, 2>::lds_bytes(12), 2, 64, 6, 512, reps, b, out, &ref);
     }
     {
         Bufs b = make(128, 10, boards);
