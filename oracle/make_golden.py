@@ -165,6 +165,33 @@ def run_case2(mct, c, mode):
     }
 
 
+def run_noise_case(mct, c, seed):
+    """search_move(noise=True) of the reference with its global np.random seeded: the move it
+    returns and the noisy policy it took the argmax of (mctree.py:177, 317-321: tau from the
+    root's ply count, 0.75 x policy + an UNSCALED Dirichlet(0.03) draw)."""
+    g = case2_game(c)
+    net = FakeNet(seed=c["net"], prior_shift=c["shift"], quant=c.get("quant", 0))
+    agent = mcts_oracle.OracleAgent(net)
+    tree = mct.SelfPlayTree(g, threads=1)
+    np.random.seed(seed)
+    bm, am = tree.search_move(agent, max_iters=c["sims"], noise=True, ai_move=True)
+    kids = tree.root.children
+    np.random.seed(seed)                                # the same draw search_move just made
+    pol = tree.compute_policy(tree.root, noise=True)
+    chosen = int(np.argmax(pol)) if len(kids) else -1
+    quiet = tree.compute_policy(tree.root, noise=False)
+    return {
+        "name": c["name"], "fen": c.get("fen"), "mode": "nep50", "noise_seed": seed,
+        "net_seed": c["net"], "prior_shift": c["shift"], "quant": c.get("quant", 0), "sims": c["sims"],
+        "prefix_moves": [m.uci() for m in g.board.move_stack],
+        "root_plies": len(g.board.move_stack),
+        "visits": [int(k.visits) for k in kids], "root_visits": int(tree.root.visits),
+        "bm": bm, "am": am, "chosen": chosen,
+        "chosen_without_noise": int(np.argmax(quiet)) if len(kids) else -1,
+        "policy_noise": [f64hex(p) for p in pol],
+    }
+
+
 def sum_terminal_visits(n):
     own = n.visits if n.state.get_result() is not None else 0
     return int(own) + sum(sum_terminal_visits(k) for k in n.children)
@@ -227,6 +254,18 @@ def main():
                              "/root/reference with a stub game module; numpy %s; roots from FENs / long "
                              "quiet games / 800 simulations" % np.__version__,
                    "cases": cases2}, f)
+    noisy = []
+    for i, c in enumerate(CASES2):
+        if c["sims"] > 200 or not case2_game(c).get_legal_moves():
+            continue
+        for rep in range(2):
+            a = run_noise_case(mct, c, 1000 + 17 * i + rep)
+            noisy.append(a)
+        print(c["name"], "noise moves", (a["bm"], a["am"]), "argmax", a["chosen"], "without noise", a["chosen_without_noise"])
+    with open(os.path.join(OUT, "mcts_noise_cases.json"), "w") as f:
+        json.dump({"source": "mctree.SelfPlayTree.search_move(noise=True) (mctree.py:159-198, 305-322) imported "
+                             "from /root/reference, np.random.seed(noise_seed) before the call; numpy %s"
+                             % np.__version__, "cases": noisy}, f)
     print("wrote", OUT)
 
 

@@ -24,6 +24,33 @@ def case_game(c):
     return g
 
 
+def test_noisy_policy_and_move_match_the_reference_with_a_seeded_global_stream(golden_dir):
+    """mcts_noise_cases.json: the reference's search_move(noise=True) after np.random.seed(s).  The
+    oracle's search (drawing from a RandomState(s), the generator behind the seeded global stream)
+    returns the same moves; the oracle's and the product's host compute_policy (chessrl_amd/engine.py:
+    pure numpy, no GPU) give the same noisy policy bit for bit, and choose_children the same argmax --
+    incl. tau < 1 roots (>= 30 plies) and cases where the noise changes the move."""
+    import numpy as np
+    from chessrl_amd import engine
+    cases = load_cases(golden_dir, "mcts_noise_cases.json")
+    assert any(c["chosen"] != c["chosen_without_noise"] for c in cases)
+    assert any(c["root_plies"] >= 30 for c in cases) and any(c["root_plies"] < 30 for c in cases)
+    for c in cases:
+        net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"], quant=c["quant"])
+        r = mcts_oracle.search(case_game(c), mcts_oracle.OracleAgent(net), c["sims"], noise=True,
+                               mode="nep50", rng=np.random.RandomState(c["noise_seed"]))
+        assert r.visits == c["visits"] and r.moves == (c["bm"], c["am"]) and r.chosen == c["chosen"], c["name"]
+        for fn in (mcts_oracle.compute_policy, engine.compute_policy):
+            pol = fn(c["visits"], c["root_visits"], c["root_plies"], noise=True,
+                     rng=np.random.RandomState(c["noise_seed"]))
+            assert [struct.pack(">d", p).hex() for p in pol] == c["policy_noise"], (c["name"], fn.__module__)
+        vis = np.zeros((1, 256), np.int64)
+        vis[0, :len(c["visits"])] = c["visits"]
+        got = engine.choose_children(vis, [len(c["visits"])], [c["root_visits"]], [c["root_plies"]], noise=True,
+                                     rngs=[np.random.RandomState(c["noise_seed"])])
+        assert got[0] == c["chosen"], c["name"]
+
+
 def hexf64(h):
     return struct.unpack(">d", bytes.fromhex(h))[0]
 
