@@ -611,6 +611,35 @@ def test_dropin_tree_matches_round2_golden_vectors(golden_dir):
         g.free()
 
 
+def test_dropin_tree_with_noise_returns_the_moves_of_the_seeded_reference(golden_dir):
+    """tests/golden/mcts_noise_cases.json: the reference's search_move(noise=True) after
+    np.random.seed(s).  The drop-in SelfPlayTree draws its Dirichlet noise on the host from the same
+    global np.random stream (mctree.py:317-321), so with the same seed it returns the same move --
+    incl. the cases where the noise overturns the visit-count argmax."""
+    import json
+    import os
+    from chessrl_amd import mctree
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.game import Game
+    cases = json.load(open(os.path.join(golden_dir, "mcts_noise_cases.json")))["cases"]
+    assert len(cases) >= 20 and any(c["chosen"] != c["chosen_without_noise"] for c in cases)
+    agents = {}
+    for c in cases:
+        key = (c["net_seed"], c["prior_shift"], c["quant"])
+        if key not in agents:
+            net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"], quant=c["quant"])
+            agents[key] = Agent(True, model=net.to("cuda:0"))
+        g = Game(board=c["fen"]) if c["fen"] else Game()
+        for u in c["prefix_moves"]:
+            assert g.move(u), (c["name"], u)
+        tree = mctree.SelfPlayTree(g, threads=1)
+        np.random.seed(c["noise_seed"])
+        mv = tree.search_move(agents[key], max_iters=c["sims"], noise=True, ai_move=True)
+        assert [k.visits for k in tree.root.children] == c["visits"], c["name"]
+        assert mv == (c["bm"], c["am"]), (c["name"], c["noise_seed"])
+        g.free()
+
+
 def test_f64_sqrt_and_divide_are_correctly_rounded():
     """The PUCT contract leans on IEEE float64 sqrt/divide on the device: check them against
     numpy through the tower-free path (a torch kernel uses the same hardware ops)."""
