@@ -192,6 +192,34 @@ def run_noise_case(mct, c, seed):
     }
 
 
+GAMES = [  # (seed of random / np.random, FakeNet seed, prior shift, simulations per move)
+    (1, 5, 26, 40), (2, 6, 28, 40), (3, 7, 24, 25), (4, 8, 27, 40), (7, 9, 26, 30), (8, 10, 29, 40),
+]
+
+
+def run_game(mct, seed, net_seed, shift, sims):
+    """One whole game by the reference's own play_game -> AgentDistributed.best_move -> SelfPlayTree
+    (noise on, global random / np.random seeded).  play_game asks for max_iters=900 (selfplay.py:76);
+    the agent here is a stub anyway, and its best_move runs the reference's best_move with `sims`
+    simulations instead so that the fixture can be replayed in seconds."""
+    import random
+    play_game, ref_best_move = ref_loader.load_play_game(mct)
+
+    class RefAgent(mcts_oracle.OracleAgent):
+        num_threads = 1
+
+        def best_move(self, game, real_game=False, max_iters=900, ai_move=True, verbose=False):
+            return ref_best_move(self, game, real_game=real_game, max_iters=sims, ai_move=ai_move, verbose=verbose)
+
+    agent = RefAgent(FakeNet(seed=net_seed, prior_shift=shift))
+    random.seed(seed)
+    np.random.seed(seed)
+    g = play_game(agent)
+    return {"seed": seed, "net_seed": net_seed, "prior_shift": shift, "sims": sims,
+            "player_color": bool(g.player_color), "moves": [m.uci() for m in g.board.move_stack],
+            "result": g.get_result(), "n_evals": agent.n_evals}
+
+
 def sum_terminal_visits(n):
     own = n.visits if n.state.get_result() is not None else 0
     return int(own) + sum(sum_terminal_visits(k) for k in n.children)
@@ -266,6 +294,17 @@ def main():
         json.dump({"source": "mctree.SelfPlayTree.search_move(noise=True) (mctree.py:159-198, 305-322) imported "
                              "from /root/reference, np.random.seed(noise_seed) before the call; numpy %s"
                              % np.__version__, "cases": noisy}, f)
+    games = []
+    for spec in GAMES:
+        gm = run_game(mct, *spec)
+        games.append(gm)
+        print("game", spec, "agent is white:", gm["player_color"], "plies", len(gm["moves"]), "result", gm["result"])
+    with open(os.path.join(OUT, "selfplay_games.json"), "w") as f:
+        json.dump({"source": "selfplay.play_game (selfplay.py:59-84) -> AgentDistributed.best_move "
+                             "(agentdistributed.py:39-68) -> mctree.SelfPlayTree, the three executed from "
+                             "/root/reference (oracle/ref_loader.py); random.seed(seed), np.random.seed(seed); "
+                             "`sims` simulations per move instead of play_game's 900; numpy %s" % np.__version__,
+                   "games": games}, f)
     print("wrote", OUT)
 
 

@@ -53,3 +53,40 @@ def load_uci_labels():
     ns = {}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), "netencoder.py", "exec"), ns)
     return ns["get_uci_labels"]()
+
+
+def _extract(path, name, cls=None):
+    """The AST node of function `name` (a method of class `cls` if given) of a reference file."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF_DIR, path)).read())
+    body = tree.body
+    if cls is not None:
+        body = [n for n in body if isinstance(n, ast.ClassDef) and n.name == cls][0].body
+    return [n for n in body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+
+
+def load_play_game(mct):
+    """(play_game, best_move): the reference's own ``selfplay.play_game`` (selfplay.py:59-84) and
+    ``AgentDistributed.best_move`` (agentdistributed.py:39-68), executed where they lie.  Their modules
+    import TensorFlow / python-chess at the top, so the two functions are taken out of the parsed
+    files and run in a namespace holding what they reference: the reference's ``mctree`` (load_mctree),
+    ``Game`` = the C-oracle duck type, a silent ``Logger``, ``random``, ``timer`` and ``np``."""
+    import ast
+    import random
+    from timeit import default_timer as timer
+    import numpy as np
+    from .chess_oracle import OracleGame
+
+    class Logger(object):
+        @staticmethod
+        def get_instance():
+            return Logger()
+
+        def debug(self, *a, **k):
+            pass
+
+    ns = {"Game": OracleGame, "Logger": Logger, "random": random, "timer": timer, "np": np, "mctree": mct}
+    for node, fname in ((_extract("selfplay.py", "play_game"), "selfplay.py"),
+                        (_extract("agentdistributed.py", "best_move", cls="AgentDistributed"), "agentdistributed.py")):
+        exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_DIR, fname), "exec"), ns)
+    return ns["play_game"], ns["best_move"]

@@ -139,6 +139,29 @@ def test_dataset_roundtrip_and_reference_shaped_play_game(tmp_path):
         g["game"].free()
 
 
+def test_dropin_play_game_replays_the_reference_games(golden_dir):
+    """tests/golden/selfplay_games.json -- whole games by the reference's own selfplay.play_game ->
+    AgentDistributed.best_move -> mctree.SelfPlayTree (noise on, seeded global streams) -- through the
+    drop-in objects on the GPU: chessrl_amd.selfplay.play_game, Agent.best_move, SelfPlayTree, Game.
+    Same colour, same moves, same result, 73 to 449 plies."""
+    import json
+    import os
+    import random
+    from chessrl_amd import selfplay
+    from chessrl_amd.agent import Agent
+    games = json.load(open(os.path.join(golden_dir, "selfplay_games.json")))["games"]
+    assert len(games) >= 6
+    for gm in games:
+        agent = Agent(True, model=FakeNet(seed=gm["net_seed"], prior_shift=gm["prior_shift"]).to("cuda:0"))
+        random.seed(gm["seed"])
+        np.random.seed(gm["seed"])
+        gam = selfplay.play_game(agent, max_iters=gm["sims"])
+        h = gam.get_history()
+        assert h["moves"] == gm["moves"], gm["seed"]
+        assert gam.get_result() == gm["result"] and bool(h["player_color"]) == gm["player_color"]
+        gam.free()
+
+
 def test_cli_plays_and_trains_rounds(tmp_path):
     """``python -m chessrl_amd.selfplay modeldir --games N`` (selfplay.py:112-163): two rounds of
     play + train; records, weights and the training log land in modeldir."""

@@ -51,6 +51,28 @@ def test_noisy_policy_and_move_match_the_reference_with_a_seeded_global_stream(g
         assert got[0] == c["chosen"], c["name"]
 
 
+def test_whole_games_match_the_reference_play_game(golden_dir):
+    """selfplay_games.json: whole games played by the reference's OWN selfplay.play_game ->
+    AgentDistributed.best_move -> mctree.SelfPlayTree (executed from /root/reference by
+    oracle/make_golden.py; noise on, random / np.random seeded).  The oracle's restatement of that
+    loop replays them move for move: colour draw, the opponent's greedy opening when the agent is
+    black, (our move, stored reply) per search, termination and result.  (Three of the six games
+    here; the GPU test replays all six through the drop-in objects.)"""
+    import random
+    import numpy as np
+    games = json.load(open(os.path.join(golden_dir, "selfplay_games.json")))["games"]
+    assert {g["player_color"] for g in games} == {True, False} and len(games) >= 6
+    picked = sorted(games, key=lambda g: len(g["moves"]) * g["sims"])[:2] + [g for g in games if g["player_color"]][:1]
+    for gm in picked:
+        agent = mcts_oracle.OracleAgent(FakeNet(seed=gm["net_seed"], prior_shift=gm["prior_shift"]))
+        random.seed(gm["seed"])
+        np.random.seed(gm["seed"])
+        og = mcts_oracle.play_game(agent, max_iters=gm["sims"], noise=True)
+        assert og.get_history()["moves"] == gm["moves"], gm["seed"]
+        assert og.get_result() == gm["result"] and bool(og.player_color) == gm["player_color"]
+        assert agent.n_evals == gm["n_evals"]
+
+
 def hexf64(h):
     return struct.unpack(">d", bytes.fromhex(h))[0]
 
