@@ -7,8 +7,11 @@ oracle's positions instead of python-chess boards.
 PARITY STATUS: ``get_uci_labels`` is pinned by a golden fixture produced from
 the reference's own function (tests/golden/uci_labels.json, made by
 oracle/make_golden.py).  ``get_game_state`` needs python-chess
-(netencoder.py:25-27,58-67), which is absent here: it is pinned only by
-hand-derived known answers -- "parity unpinned" by the reference.
+(netencoder.py:25-27,58-67), which is absent here: it is pinned by
+tests/golden/encoder_cases.json = the reference's own get_game_state and helpers
+executed over an adapter of the four python-chess members they touch
+(oracle/ref_loader.py: pieces, mirror, tolist, pop) -- the layout is the
+reference's, the reading of those four primitives is ours.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.

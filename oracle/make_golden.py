@@ -220,6 +220,30 @@ def run_game(mct, seed, net_seed, shift, sims):
             "result": g.get_result(), "n_evals": agent.n_evals}
 
 
+ENCODER_CASES = [  # (prefix seed, plies) from the standard position, or a FEN root + pushed moves
+    (1, 0), (2, 1), (3, 2), (4, 7), (5, 8), (6, 9), (7, 15), (8, 40), (9, 91), (10, 150),
+    {"fen": "r3k2r/pPp2ppp/8/3pP3/8/8/P1P2PpP/R3K2R w KQkq d6", "moves": ["e5d6", "g2h1n", "b7a8q"]},
+    {"fen": "8/8/8/4k3/8/8/4K3/7R b", "moves": []},
+]
+
+
+def encoder_case(ref_encode, spec):
+    if isinstance(spec, dict):
+        g = OracleGame(board=board_from_fen(spec["fen"]))
+        for u in spec["moves"]:
+            assert g.move(u), u
+        fen, pre = spec["fen"], list(spec["moves"])
+    else:
+        g = prefix_game(*spec)
+        fen, pre = None, [m.uci() for m in g.board.move_stack]
+    planes = np.asarray(ref_encode(g))
+    assert planes.shape == (8, 8, 127) and set(np.unique(planes)) <= {0.0, 1.0}
+    return {"fen": fen, "prefix_moves": pre, "turn": bool(g.turn),
+            # (8, 8, 127) of 0/1 -> np.packbits over the flattened [row][col][channel] order
+            "planes_packbits_hex": np.packbits(planes.astype(np.uint8).reshape(-1)).tobytes().hex(),
+            "ones": int(planes.sum())}
+
+
 def sum_terminal_visits(n):
     own = n.visits if n.state.get_result() is not None else 0
     return int(own) + sum(sum_terminal_visits(k) for k in n.children)
@@ -294,6 +318,14 @@ def main():
         json.dump({"source": "mctree.SelfPlayTree.search_move(noise=True) (mctree.py:159-198, 305-322) imported "
                              "from /root/reference, np.random.seed(noise_seed) before the call; numpy %s"
                              % np.__version__, "cases": noisy}, f)
+    ref_encode = ref_loader.load_encoder()
+    enc = [encoder_case(ref_encode, spec) for spec in ENCODER_CASES]
+    with open(os.path.join(OUT, "encoder_cases.json"), "w") as f:
+        json.dump({"source": "netencoder.get_game_state and helpers (netencoder.py:13-91), taken out of the parsed "
+                             "reference file and executed over oracle/ref_loader.py's adapter of the four "
+                             "python-chess Board / SquareSet members they use (pieces, mirror, tolist, pop); the "
+                             "positions come from the C oracle", "cases": enc}, f)
+    print("encoder cases", len(enc), "ones per case", [e["ones"] for e in enc])
     games = []
     for spec in GAMES:
         gm = run_game(mct, *spec)

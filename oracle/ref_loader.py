@@ -90,3 +90,62 @@ def load_play_game(mct):
                         (_extract("agentdistributed.py", "best_move", cls="AgentDistributed"), "agentdistributed.py")):
         exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_DIR, fname), "exec"), ns)
     return ns["play_game"], ns["best_move"]
+
+
+class _SquareSet(object):
+    """What netencoder.py:25-26 touches of a python-chess SquareSet: ``mirror()`` (the documented
+    'vertically mirrored copy': rank r <-> rank 9-r) and ``tolist()`` (64 bools, squares a1..h8)."""
+
+    def __init__(self, bb):
+        self.bb = bb & 0xFFFFFFFFFFFFFFFF
+
+    def mirror(self):
+        return _SquareSet(int.from_bytes(self.bb.to_bytes(8, "little"), "big"))
+
+    def tolist(self):
+        return [bool((self.bb >> sq) & 1) for sq in range(64)]
+
+
+class _BoardAdapter(object):
+    """The four python-chess ``Board`` members the reference's encoder uses (netencoder.py:25,57,62;
+    ``pieces(piece_type, color)`` with PAWN..KING = 1..6, ``copy()``, ``pop()`` raising IndexError on
+    an empty move stack) over the C oracle's position history.  This adapter is the part of the
+    encoder pin that is NOT the reference's code."""
+
+    def __init__(self, game, back=0):
+        self._g, self._back = game, back
+
+    def pieces(self, piece_type, color):
+        b = self._g.board_at(self._back)
+        occ = 0
+        for t in range(6):
+            occ |= int(b.bb[t])
+        own = int(b.white) if color else (occ & ~int(b.white))
+        return _SquareSet(int(b.bb[piece_type - 1]) & own)
+
+    def copy(self):
+        return _BoardAdapter(self._g, self._back)
+
+    def pop(self):
+        if self._back + 1 > len(self._g):
+            raise IndexError("pop from empty list")
+        self._back += 1
+
+
+class _GameAdapter(object):
+    def __init__(self, game):
+        self.board, self.turn = _BoardAdapter(game), game.turn
+
+
+def load_encoder():
+    """The reference's own ``get_game_state`` and its helpers (netencoder.py:13-91), taken out of
+    the parsed file (its imports need python-chess and TensorFlow) and executed in a namespace with
+    ``np`` and a ``chess`` that only has PIECE_TYPES = 1..6; call it on an OracleGame."""
+    import ast
+    import numpy as np
+    ns = {"np": np, "chess": types.SimpleNamespace(PIECE_TYPES=range(1, 7))}
+    nodes = [_extract("netencoder.py", n) for n in
+             ("_get_pieces_one_hot", "_get_current_game_state", "_get_game_history", "get_game_state")]
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), os.path.join(REF_DIR, "netencoder.py"), "exec"), ns)
+    fn = ns["get_game_state"]
+    return lambda game, flipped=False: fn(_GameAdapter(game), flipped=flipped)

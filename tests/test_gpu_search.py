@@ -57,6 +57,44 @@ def test_encoder_matches_oracle():
     eng.close()
 
 
+def test_encoder_matches_the_reference_encoder_vectors(golden_dir):
+    """tests/golden/encoder_cases.json (the reference's own get_game_state, see
+    tests/test_oracle_chess.py) through the HIP encoder: drop-in Games built from FEN + moves,
+    copied into an engine, crl_encode in both plane formats."""
+    import json
+    import os
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.game import Game
+    cases = json.load(open(os.path.join(golden_dir, "encoder_cases.json")))["cases"]
+    games = []
+    for c in cases:
+        g = Game(board=c["fen"]) if c["fen"] else Game()
+        for u in c["prefix_moves"]:
+            assert g.move(u), u
+        games.append(g)
+    n = (len(games) + 3) // 4 * 4
+    for bits in (False, True):
+        eng = LockstepEngine(lambda p: None, n_games=n, max_sims=4, use_graph=False, bitplanes=bits)
+        eng.load_games(games)
+        eng.ctx.encode(eng.planes_s1.data_ptr())
+        eng.ctx.sync()
+        if bits:
+            raw = eng.planes_s1.cpu().numpy().view(np.uint64)                 # [n][128] plane bitboards
+            got = np.zeros((n, 8, 8, 128), np.float32)
+            for ch in range(128):
+                for sq in range(64):
+                    got[:, 7 - sq // 8, sq % 8, ch] = (raw[:, ch] >> np.uint64(sq)) & np.uint64(1)
+        else:
+            got = eng.planes_s1.float().cpu().numpy()
+        for i, c in enumerate(cases):
+            ref = np.unpackbits(np.frombuffer(bytes.fromhex(c["planes_packbits_hex"]), np.uint8))[:8 * 8 * 127]
+            assert np.array_equal(got[i, :, :, :127].reshape(-1), ref.astype(np.float32)), (bits, i)
+            assert not got[i, :, :, 127].any()
+        eng.close()
+    for g in games:
+        g.free()
+
+
 @pytest.mark.parametrize("mode", ["nep50", "legacy"])
 @pytest.mark.parametrize("shift,quant,sims,graph", [(24, 0, 60, False), (29, 0, 150, True),
                                                     (33, 12, 150, True), (31, 16, 90, False)])

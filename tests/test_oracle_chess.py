@@ -125,3 +125,26 @@ def test_python_chess_readme_known_answers():
     # README "Make and unmake moves": Nf3 is legal at the start, a8a1 is not
     s = OracleGame()
     assert "g1f3" in s.get_legal_moves() and not s.move("a8a1") and len(s.get_legal_moves()) == 20
+
+
+def test_encoder_oracle_matches_the_reference_encoder(golden_dir):
+    """encoder_cases.json: the reference's own netencoder.get_game_state (and helpers, netencoder.py:
+    13-91), executed by oracle/make_golden.py over an adapter of the four python-chess Board /
+    SquareSet members it touches.  Plane order, colour order, the per-colour 'empty' plane, the
+    history stack (0, 1, 2, 7, 8, 9 ... 150 plies back, zeros where there is none; a FEN root with
+    en passant and promotions) and the side-to-move plane."""
+    import json
+    import os
+    import numpy as np
+    from oracle import encoder_oracle
+    cases = json.load(open(os.path.join(golden_dir, "encoder_cases.json")))["cases"]
+    assert len(cases) >= 12
+    for c in cases:
+        g = OracleGame(board=board_from_fen(c["fen"])) if c["fen"] else OracleGame()
+        for u in c["prefix_moves"]:
+            assert g.move(u)
+        ref = np.unpackbits(np.frombuffer(bytes.fromhex(c["planes_packbits_hex"]), np.uint8))[:8 * 8 * 127]
+        mine = encoder_oracle.get_game_state(g)
+        assert mine.shape == (8, 8, 127) and int(mine.sum()) == c["ones"]
+        assert np.array_equal(mine.reshape(-1), ref.astype(np.float64)), (c["fen"], len(c["prefix_moves"]))
+        assert bool(mine[0, 0, 126]) == c["turn"]
