@@ -201,17 +201,12 @@ def run_game(mct, seed, net_seed, shift, sims):
     """One whole game by the reference's own play_game -> AgentDistributed.best_move -> SelfPlayTree
     (noise on, global random / np.random seeded).  play_game asks for max_iters=900 (selfplay.py:76);
     the agent here is a stub anyway, and its best_move runs the reference's best_move with `sims`
-    simulations instead so that the fixture can be replayed in seconds."""
+    simulations instead so that the fixture can be replayed in seconds (ref_loader.make_reference_agent)."""
     import random
-    play_game, ref_best_move = ref_loader.load_play_game(mct)
-
-    class RefAgent(mcts_oracle.OracleAgent):
-        num_threads = 1
-
-        def best_move(self, game, real_game=False, max_iters=900, ai_move=True, verbose=False):
-            return ref_best_move(self, game, real_game=real_game, max_iters=sims, ai_move=ai_move, verbose=verbose)
-
-    agent = RefAgent(FakeNet(seed=net_seed, prior_shift=shift))
+    play_game, _ = ref_loader.load_play_game(mct)
+    # best_move, predict_policy, predict_outcome, predict: the reference's; the network round trip
+    # encodes with the reference's get_game_state and evaluates FakeNet
+    agent = ref_loader.make_reference_agent(mct, FakeNet(seed=net_seed, prior_shift=shift), sims)
     random.seed(seed)
     np.random.seed(seed)
     g = play_game(agent)

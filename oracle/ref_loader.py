@@ -86,10 +86,65 @@ def load_play_game(mct):
             pass
 
     ns = {"Game": OracleGame, "Logger": Logger, "random": random, "timer": timer, "np": np, "mctree": mct}
-    for node, fname in ((_extract("selfplay.py", "play_game"), "selfplay.py"),
-                        (_extract("agentdistributed.py", "best_move", cls="AgentDistributed"), "agentdistributed.py")):
+    nodes = [(_extract("selfplay.py", "play_game"), "selfplay.py")]
+    for meth in AGENT_METHODS:
+        nodes.append((_extract("agentdistributed.py", meth, cls="AgentDistributed"), "agentdistributed.py"))
+    for node, fname in nodes:
         exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_DIR, fname), "exec"), ns)
     return ns["play_game"], ns["best_move"]
+
+
+# AgentDistributed methods executed from the reference (agentdistributed.py:39-90); compiled outside
+# their class, so ``self.__send_game`` is looked up under that literal name
+AGENT_METHODS = ("best_move", "predict_outcome", "predict_policy", "predict")
+
+
+def make_reference_agent(mct, net, sims):
+    """An agent whose best_move / predict_policy / predict_outcome / predict ARE the reference's
+    (see load_play_game), whose ``uci_dict`` is built from the reference's get_uci_labels and whose
+    ``__send_game`` -- the TCP round trip to the prediction worker in the reference -- encodes the game
+    with the reference's own get_game_state (load_encoder) and evaluates ``net`` on it.  ``best_move``
+    runs with ``sims`` simulations whatever max_iters the caller passes (play_game says 900)."""
+    import ast
+    import numpy as np
+    import torch
+    ns = {"np": np, "mctree": mct}
+    for meth in AGENT_METHODS:
+        node = _extract("agentdistributed.py", meth, cls="AgentDistributed")
+        exec(compile(ast.Module(body=[node], type_ignores=[]), os.path.join(REF_DIR, "agentdistributed.py"), "exec"), ns)
+    encode = load_encoder()
+    labels = load_uci_labels()
+    ref_best_move = ns["best_move"]
+
+    class ReferenceAgent(object):
+        num_threads = 1
+        predict_outcome, predict_policy, predict = ns["predict_outcome"], ns["predict_policy"], ns["predict"]
+
+        def __init__(self, color=True):
+            self.color = color
+            self.move_encodings = labels
+            self.uci_dict = {u: i for i, u in enumerate(labels)}
+            self.n_evals = 0
+
+        def best_move(self, game, real_game=False, max_iters=900, ai_move=True, verbose=False):
+            return ref_best_move(self, game, real_game=real_game, max_iters=sims, ai_move=ai_move, verbose=verbose)
+
+        def _send(self, game):
+            pol, val = net(torch.from_numpy(np.asarray(encode(game))[None]))
+            self.n_evals += 1
+            return pol[0].cpu().numpy().astype(np.float32), float(val[0])
+
+        def get_copy(self):
+            return self
+
+        def connect(self):
+            pass
+
+        def disconnect(self):
+            pass
+
+    setattr(ReferenceAgent, "__send_game", ReferenceAgent._send)
+    return ReferenceAgent()
 
 
 class _SquareSet(object):
