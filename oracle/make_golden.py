@@ -215,6 +215,25 @@ def run_game(mct, seed, net_seed, shift, sims):
             "result": g.get_result(), "n_evals": agent.n_evals}
 
 
+def dataset_case(ds_mod, gm, date):
+    """dataset.DatasetGame of the reference (dataset.py:7-97) on one of the golden games: the JSON
+    text it serialises, what loads() makes of that text, and augment_game's expansion."""
+    g = OracleGame(player_color=gm["player_color"], date=date)
+    for u in gm["moves"]:
+        assert g.move(u)
+    ds = ds_mod.DatasetGame()
+    ds.append(g)
+    text = str(ds)
+    back = ds_mod.DatasetGame()
+    back.loads(text)
+    assert len(back) == 1 and str(back) == text
+    aug = ds.augment_game(g)
+    return {"seed": gm["seed"], "date": date, "player_color": gm["player_color"], "moves": gm["moves"],
+            "json": text,
+            "augment": [{"plies": len(a["game"]), "fen": a["game"].get_fen(), "next_move": a["next_move"],
+                         "result": a["result"]} for a in aug]}
+
+
 ENCODER_CASES = [  # (prefix seed, plies) from the standard position, or a FEN root + pushed moves
     (1, 0), (2, 1), (3, 2), (4, 7), (5, 8), (6, 9), (7, 15), (8, 40), (9, 91), (10, 150),
     {"fen": "r3k2r/pPp2ppp/8/3pP3/8/8/P1P2PpP/R3K2R w KQkq d6", "moves": ["e5d6", "g2h1n", "b7a8q"]},
@@ -332,6 +351,12 @@ def main():
                              "/root/reference (oracle/ref_loader.py); random.seed(seed), np.random.seed(seed); "
                              "`sims` simulations per move instead of play_game's 900; numpy %s" % np.__version__,
                    "games": games}, f)
+    ds_mod = ref_loader.load_dataset()
+    dsc = [dataset_case(ds_mod, gm, "01/02/2020 03:04:05") for gm in sorted(games, key=lambda x: len(x["moves"]))[:2]]
+    with open(os.path.join(OUT, "dataset_cases.json"), "w") as f:
+        json.dump({"source": "dataset.DatasetGame (dataset.py:7-97) imported from /root/reference with the stub game "
+                             "module, on two of the games of selfplay_games.json", "cases": dsc}, f)
+    print("dataset cases", [(c["seed"], len(c["augment"])) for c in dsc])
     print("wrote", OUT)
 
 

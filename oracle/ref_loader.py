@@ -44,6 +44,29 @@ def load_mctree():
     return mod
 
 
+def load_dataset():
+    """The reference's own ``dataset.py`` (it imports only ``game`` and ``json``), imported where it
+    lies with the same stub ``game`` module as mctree (Game = the C-oracle duck type)."""
+    from .chess_oracle import OracleGame
+    stub = types.ModuleType("game")
+    stub.Game = OracleGame
+    saved = {k: sys.modules.get(k) for k in ("game", "dataset")}
+    sys.modules["game"] = stub
+    sys.modules.pop("dataset", None)
+    sys.path.insert(0, REF_DIR)
+    try:
+        mod = importlib.import_module("dataset")
+    finally:
+        sys.path.remove(REF_DIR)
+        sys.modules.pop("dataset", None)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
 def load_uci_labels():
     """exec the pure function netencoder.get_uci_labels (netencoder.py:94-134)."""
     import ast

@@ -162,6 +162,35 @@ def test_dropin_play_game_replays_the_reference_games(golden_dir):
         gam.free()
 
 
+def test_dataset_matches_the_reference_dataset_module(golden_dir):
+    """tests/golden/dataset_cases.json -- the reference's own dataset.DatasetGame (imported from
+    /root/reference by oracle/make_golden.py) on two of the golden games: the JSON text it writes,
+    loads() of that text, and augment_game's (position, next move, result) expansion -- against
+    chessrl_amd.dataset.DatasetGame on HIP-backed Games."""
+    import json
+    import os
+    from chessrl_amd.dataset import DatasetGame
+    from chessrl_amd.game import Game
+    for c in json.load(open(os.path.join(golden_dir, "dataset_cases.json")))["cases"]:
+        g = Game(player_color=c["player_color"], date=c["date"])
+        for u in c["moves"]:
+            assert g.move(u)
+        d = DatasetGame()
+        d.append(g)
+        assert str(d) == c["json"]
+        back = DatasetGame()
+        back.loads(c["json"])
+        assert len(back) == 1 and str(back) == c["json"]
+        aug = d.augment_game(g)
+        assert len(aug) == len(c["augment"])
+        for a, e in zip(aug, c["augment"]):
+            assert (len(a["game"]), a["game"].get_fen(), a["next_move"], a["result"]) == \
+                (e["plies"], e["fen"], e["next_move"], e["result"])
+            a["game"].free()
+        back[0].free()
+        g.free()
+
+
 def test_cli_plays_and_trains_rounds(tmp_path):
     """``python -m chessrl_amd.selfplay modeldir --games N`` (selfplay.py:112-163): two rounds of
     play + train; records, weights and the training log land in modeldir."""
