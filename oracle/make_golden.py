@@ -234,6 +234,23 @@ def dataset_case(ds_mod, gm, date):
                          "result": a["result"]} for a in aug]}
 
 
+def sequence_case(ds_mod, seq_cls, dsc, seed, flips):
+    """One batch of the reference's DataGameSequence over the two dataset_cases games."""
+    ds = ds_mod.DatasetGame()
+    ds.loads("[" + ", ".join(c["json"][1:-1] for c in dsc) + "]")
+    seq = seq_cls(ds, batch_size=2, random_flips=flips)
+    assert len(seq) == 1
+    np.random.seed(seed)
+    x, (pol, val) = seq[0]
+    assert x.shape[1:] == (8, 8, 127) and pol.shape == (x.shape[0], 1968) and pol.dtype == np.float32
+    assert (pol.sum(1) == 1).all()
+    return {"seed": seed, "random_flips": flips, "n": int(x.shape[0]), "x_dtype": str(x.dtype),
+            "x_sha256": hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest(),
+            "first_sample_of_each_game_packbits_hex": [
+                np.packbits(x[i].astype(np.uint8).reshape(-1)).tobytes().hex() for i in (0, len(dsc[0]["moves"]))],
+            "labels": [int(i) for i in pol.argmax(1)], "values": [int(v) for v in val]}
+
+
 ENCODER_CASES = [  # (prefix seed, plies) from the standard position, or a FEN root + pushed moves
     (1, 0), (2, 1), (3, 2), (4, 7), (5, 8), (6, 9), (7, 15), (8, 40), (9, 91), (10, 150),
     {"fen": "r3k2r/pPp2ppp/8/3pP3/8/8/P1P2PpP/R3K2R w KQkq d6", "moves": ["e5d6", "g2h1n", "b7a8q"]},
@@ -357,6 +374,14 @@ def main():
         json.dump({"source": "dataset.DatasetGame (dataset.py:7-97) imported from /root/reference with the stub game "
                              "module, on two of the games of selfplay_games.json", "cases": dsc}, f)
     print("dataset cases", [(c["seed"], len(c["augment"])) for c in dsc])
+    seq_cls = ref_loader.load_data_sequence(ds_mod)
+    seqs = [sequence_case(ds_mod, seq_cls, dsc, seed, flips) for seed, flips in ((3, 0.0), (1, 0.5), (6, 0.5), (2, 0.5))]
+    with open(os.path.join(OUT, "sequence_cases.json"), "w") as f:
+        json.dump({"source": "netencoder.DataGameSequence (netencoder.py:137-181) taken out of the parsed reference "
+                             "file and executed (oracle/ref_loader.py) over the reference's dataset.DatasetGame of "
+                             "the two games of dataset_cases.json; batch_size 2, np.random.seed(seed) before seq[0]",
+                   "cases": seqs}, f)
+    print("sequence cases", [(c["seed"], c["n"], c["x_sha256"][:8]) for c in seqs])
     print("wrote", OUT)
 
 

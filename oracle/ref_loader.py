@@ -227,3 +227,25 @@ def load_encoder():
     exec(compile(ast.Module(body=nodes, type_ignores=[]), os.path.join(REF_DIR, "netencoder.py"), "exec"), ns)
     fn = ns["get_game_state"]
     return lambda game, flipped=False: fn(_GameAdapter(game), flipped=flipped)
+
+
+def load_data_sequence(ds_mod):
+    """The reference's own training-batch generator ``DataGameSequence`` (netencoder.py:137-181),
+    taken out of the parsed file and executed with the reference's get_game_state (over the adapter
+    above), get_uci_labels, ``Sequence = object`` and Keras' documented ``to_categorical`` (a float32
+    one-hot vector) in its namespace.  Games are the C-oracle duck type, wrapped for the encoder."""
+    import ast
+    import numpy as np
+    encode = load_encoder()
+
+    def to_categorical(y, num_classes=None):
+        v = np.zeros(num_classes, dtype=np.float32)
+        v[int(y)] = 1.0
+        return v
+
+    tree = ast.parse(open(os.path.join(REF_DIR, "netencoder.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DataGameSequence"][0]
+    ns = {"np": np, "Sequence": object, "to_categorical": to_categorical, "get_uci_labels": load_uci_labels,
+          "get_game_state": lambda game, flipped=False: encode(game, flipped=flipped)}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), os.path.join(REF_DIR, "netencoder.py"), "exec"), ns)
+    return ns["DataGameSequence"]

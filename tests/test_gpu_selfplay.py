@@ -191,6 +191,40 @@ def test_dataset_matches_the_reference_dataset_module(golden_dir):
         g.free()
 
 
+def test_training_batches_match_the_reference_data_sequence(golden_dir):
+    """tests/golden/sequence_cases.json -- the reference's own netencoder.DataGameSequence (taken out of
+    the parsed file and executed by oracle/make_golden.py over the reference's DatasetGame,
+    get_game_state and label table) -- against chessrl_amd.netencoder.DataGameSequence, whose planes
+    come from ONE launch of the HIP sequence-replay + encoder kernels: same 391 samples, same
+    180-degree flips for the same np.random seed (neither game, either, both), same labels, results."""
+    import hashlib
+    import json
+    import os
+    from chessrl_amd.dataset import DatasetGame
+    from chessrl_amd.netencoder import DataGameSequence
+    dsc = json.load(open(os.path.join(golden_dir, "dataset_cases.json")))["cases"]
+    cases = json.load(open(os.path.join(golden_dir, "sequence_cases.json")))["cases"]
+    assert len({c["x_sha256"] for c in cases}) == 4
+    ds = DatasetGame()
+    ds.loads("[" + ", ".join(c["json"][1:-1] for c in dsc) + "]")
+    assert len(ds) == 2
+    for c in cases:
+        seq = DataGameSequence(ds, batch_size=2, random_flips=c["random_flips"])
+        assert len(seq) == 1
+        np.random.seed(c["seed"])
+        x, (pol, val) = seq[0]
+        assert x.shape == (c["n"], 8, 8, 127) and str(x.dtype) == c["x_dtype"] and pol.dtype == np.float32
+        for k, i in enumerate((0, len(dsc[0]["moves"]))):
+            ref = np.unpackbits(np.frombuffer(bytes.fromhex(c["first_sample_of_each_game_packbits_hex"][k]), np.uint8))
+            assert np.array_equal(x[i].reshape(-1), ref[:8 * 8 * 127].astype(x.dtype)), (c["seed"], k)
+        assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == c["x_sha256"], c["seed"]
+        assert pol.shape == (c["n"], 1968) and (pol.sum(1) == 1).all()
+        assert [int(i) for i in pol.argmax(1)] == c["labels"]
+        assert [int(v) for v in val] == c["values"]
+    for g in ds.games:
+        g.free()
+
+
 def test_cli_plays_and_trains_rounds(tmp_path):
     """``python -m chessrl_amd.selfplay modeldir --games N`` (selfplay.py:112-163): two rounds of
     play + train; records, weights and the training log land in modeldir."""
