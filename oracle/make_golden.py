@@ -382,6 +382,13 @@ def main():
                              "the two games of dataset_cases.json; batch_size 2, np.random.seed(seed) before seq[0]",
                    "cases": seqs}, f)
     print("sequence cases", [(c["seed"], c["n"], c["x_sha256"][:8]) for c in seqs])
+    graph = ref_loader.record_model_graph()
+    with open(os.path.join(OUT, "model_graph.json"), "w") as f:
+        json.dump({"source": "ChessModel.__init__ and __res_block (model.py:17-72,111-122) executed from /root/reference "
+                             "over recording stand-ins of the Keras constructors (oracle/ref_loader.record_model_graph): "
+                             "the layers the reference builds, their arguments and wiring, and the compile() call",
+                   "graph": graph}, f)
+    print("model graph", len(graph["nodes"]), "nodes")
     print("wrote", OUT)
 
 

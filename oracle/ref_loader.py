@@ -249,3 +249,61 @@ def load_data_sequence(ds_mod):
           "get_game_state": lambda game, flipped=False: encode(game, flipped=flipped)}
     exec(compile(ast.Module(body=[cls], type_ignores=[]), os.path.join(REF_DIR, "netencoder.py"), "exec"), ns)
     return ns["DataGameSequence"]
+
+
+def record_model_graph():
+    """Execute the reference's own ``ChessModel.__init__`` and ``__res_block`` (model.py:17-72,111-122)
+    over RECORDING stand-ins of the Keras constructors they call (Input, Conv2D, BatchNormalization,
+    Activation, Flatten, Dense, Add, Model, Adam): no arithmetic, only which layer is built with which
+    arguments on which inputs, and what ``compile`` is given.  Returns {"nodes": [...], "outputs": [...],
+    "compile": {...}} -- the topology and hyper-parameters as the reference code states them (what
+    Keras then does with 'l2', BatchNormalization() defaults etc. is Keras documentation, not pinned)."""
+    import ast
+    nodes = []
+
+    class T(object):                                    # a symbolic tensor = the id of the node that made it
+        def __init__(self, i):
+            self.id = i
+
+    def layer(op):
+        def ctor(*args, **kw):
+            cfg = dict(kw)
+            if args:
+                cfg["args"] = [list(a) if isinstance(a, tuple) else a for a in args]
+
+            def call(x):
+                ins = [t.id for t in x] if isinstance(x, (list, tuple)) else [x.id]
+                nodes.append({"op": op, "config": cfg, "inputs": ins})
+                return T(len(nodes) - 1)
+            return call
+        return ctor
+
+    def Input(shape):
+        nodes.append({"op": "Input", "config": {"shape": list(shape)}, "inputs": []})
+        return T(len(nodes) - 1)
+
+    rec = {}
+
+    class Model(object):
+        def __init__(self, inp, outs):
+            rec["inputs"], rec["outputs"] = [inp.id], [o.id for o in outs]
+
+        def load_weights(self, path):
+            rec["load_weights"] = path
+
+        def compile(self, optimizer, loss=None, metrics=None):
+            rec["compile"] = {"optimizer": optimizer, "loss": loss, "metrics": metrics}
+
+    ns = {"Input": Input, "Model": Model, "Adam": lambda **kw: {"class": "Adam", **kw}}
+    for op in ("Conv2D", "BatchNormalization", "Activation", "Flatten", "Dense", "Add"):
+        ns[op] = layer(op)
+    init = _extract("model.py", "__init__", cls="ChessModel")
+    blk = _extract("model.py", "__res_block", cls="ChessModel")
+    exec(compile(ast.Module(body=[init, blk], type_ignores=[]), os.path.join(REF_DIR, "model.py"), "exec"), ns)
+
+    class Self(object):
+        pass
+    me = Self()
+    setattr(Self, "__res_block", ns["__res_block"])      # compiled outside the class: no name mangling
+    ns["__init__"](me, compile_model=True, weights=None)
+    return {"nodes": nodes, "inputs": rec["inputs"], "outputs": rec["outputs"], "compile": rec["compile"]}
