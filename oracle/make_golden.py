@@ -251,6 +251,42 @@ def sequence_case(ds_mod, seq_cls, dsc, seed, flips):
             "labels": [int(i) for i in pol.argmax(1)], "values": [int(v) for v in val]}
 
 
+def game_agent_case(mct, agent_white, net_seed, human_seed):
+    """The reference's own GameAgent (gameagent.py:7-50) against an agent made of the reference's
+    best_move / predict_policy (ref_loader.make_reference_agent): a scripted human plays seeded random
+    legal moves, tries an illegal move before each of them, and (white agent) a first call whose
+    argument is ignored.  Every call: argument, return value, plies afterwards."""
+    GameAgent, AgentBase = ref_loader.load_game_agent()
+    inner = ref_loader.make_reference_agent(mct, FakeNet(seed=net_seed, prior_shift=30), 1)
+
+    class ScriptAgent(AgentBase):
+        color = agent_white
+
+        def best_move(self, game, real_game=False, **kw):
+            return inner.best_move(game, real_game=real_game, **kw)
+
+    g = GameAgent(ScriptAgent(), player_color=not agent_white)
+    rng = np.random.default_rng(human_seed)
+    calls = []
+
+    def call(mv):
+        ok = g.move(mv)
+        calls.append({"move": mv, "returned": bool(ok), "plies": len(g)})
+
+    if agent_white:
+        call("a7a6")
+    for _ in range(40):
+        if g.get_result() is not None:
+            break
+        call("a1a1")
+        lm = g.get_legal_moves()
+        call(lm[int(rng.integers(len(lm)))])
+    copy = g.get_copy()
+    return {"agent_white": agent_white, "net_seed": net_seed, "prior_shift": 30, "human_seed": human_seed, "calls": calls,
+            "moves": g.get_history()["moves"], "result": g.get_result(),
+            "copy_is_game_agent": type(copy).__name__ == "GameAgent", "copy_moves": copy.get_history()["moves"]}
+
+
 ENCODER_CASES = [  # (prefix seed, plies) from the standard position, or a FEN root + pushed moves
     (1, 0), (2, 1), (3, 2), (4, 7), (5, 8), (6, 9), (7, 15), (8, 40), (9, 91), (10, 150),
     {"fen": "r3k2r/pPp2ppp/8/3pP3/8/8/P1P2PpP/R3K2R w KQkq d6", "moves": ["e5d6", "g2h1n", "b7a8q"]},
@@ -382,6 +418,12 @@ def main():
                              "the two games of dataset_cases.json; batch_size 2, np.random.seed(seed) before seq[0]",
                    "cases": seqs}, f)
     print("sequence cases", [(c["seed"], c["n"], c["x_sha256"][:8]) for c in seqs])
+    gac = [game_agent_case(mct, aw, ns_, hs) for aw, ns_, hs in ((True, 41, 12), (False, 41, 12), (True, 42, 13), (False, 43, 14))]
+    with open(os.path.join(OUT, "game_agent_cases.json"), "w") as f:
+        json.dump({"source": "gameagent.GameAgent (gameagent.py:7-50), its class statement executed from /root/reference "
+                             "(oracle/ref_loader.load_game_agent) against an agent made of the reference's best_move / "
+                             "predict_policy and FakeNet", "cases": gac}, f)
+    print("game agent cases", [(c["agent_white"], len(c["calls"]), len(c["moves"])) for c in gac])
     graph = ref_loader.record_model_graph()
     with open(os.path.join(OUT, "model_graph.json"), "w") as f:
         json.dump({"source": "ChessModel.__init__ and __res_block (model.py:17-72,111-122) executed from /root/reference "

@@ -307,3 +307,49 @@ def record_model_graph():
     setattr(Self, "__res_block", ns["__res_block"])      # compiled outside the class: no name mangling
     ns["__init__"](me, compile_model=True, weights=None)
     return {"nodes": nodes, "inputs": rec["inputs"], "outputs": rec["outputs"], "compile": rec["compile"]}
+
+
+def load_game_agent():
+    """(GameAgent class, Agent marker class): the reference's own ``GameAgent`` (gameagent.py:7-50),
+    its class statement taken out of the parsed file and executed with ``Game`` = the C-oracle duck
+    type whose ``board`` also has ``push`` (python-chess ``Board.push`` of a legal move), ``chess.Move.
+    from_uci`` = the identity on UCI strings, and ``Agent`` = a marker class the test agent derives from."""
+    import ast
+    from .chess_oracle import OracleGame
+
+    class _PushBoard(object):
+        def __init__(self, game):
+            self._g, self._view = game, game.board
+
+        @property
+        def move_stack(self):
+            return self._view.move_stack
+
+        @property
+        def turn(self):
+            return self._view.turn
+
+        def push(self, uci):
+            assert OracleGame.move(self._g, uci), uci
+
+        def copy(self):
+            return self._g
+
+    class Game(OracleGame):
+        def __init__(self, board=None, player_color=True, date=None):
+            if isinstance(board, OracleGame):            # gameagent.py:46: GameAgent(board=self.board.copy(), ...)
+                src = OracleGame.get_copy(board)
+                OracleGame.__init__(self, player_color=player_color, date=date, _handle=src._h)
+                src._h = None
+            else:
+                OracleGame.__init__(self, board=board, player_color=player_color, date=date)
+            self.board = _PushBoard(self)
+
+    class Agent(object):
+        pass
+
+    tree = ast.parse(open(os.path.join(REF_DIR, "gameagent.py")).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "GameAgent"][0]
+    ns = {"Game": Game, "Agent": Agent, "chess": types.SimpleNamespace(Move=types.SimpleNamespace(from_uci=lambda u: u))}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), os.path.join(REF_DIR, "gameagent.py"), "exec"), ns)
+    return ns["GameAgent"], Agent

@@ -283,6 +283,29 @@ def test_game_agent_interactive_surface(agent_white):
     g.tearup()
 
 
+def test_game_agent_replays_the_reference_game_agent(golden_dir):
+    """tests/golden/game_agent_cases.json -- the reference's own GameAgent class (gameagent.py:7-50,
+    executed by oracle/make_golden.py) driven by a scripted human: every ``move`` call's argument,
+    return value and ply count afterwards (ignored first argument when the agent is white, refused
+    illegal moves, the agent's greedy answers), the final move list and ``get_copy``."""
+    import json
+    import os
+    from chessrl_amd.agent import Agent
+    from chessrl_amd.gameagent import GameAgent
+    for c in json.load(open(os.path.join(golden_dir, "game_agent_cases.json")))["cases"]:
+        net = FakeNet(seed=c["net_seed"], prior_shift=c["prior_shift"])
+        g = GameAgent(Agent(c["agent_white"], model=net.to("cuda:0")), player_color=not c["agent_white"])
+        for call in c["calls"]:
+            assert g.move(call["move"]) is call["returned"], call
+            assert len(g) == call["plies"], call
+        assert g.get_history()["moves"] == c["moves"] and g.get_result() == c["result"]
+        cp = g.get_copy()
+        assert isinstance(cp, GameAgent) is c["copy_is_game_agent"]
+        assert cp.get_history()["moves"] == c["copy_moves"]
+        cp.free()
+        g.tearup()
+
+
 def test_compaction_of_a_thinning_batch_keeps_every_game_identical():
     """A finite run stops refilling; the runner then halves the lockstep batch as games end
     (copying the running games into the first slots).  Records must not depend on that, and three
