@@ -99,7 +99,6 @@ def _run_graph(graph, w, planes):
 @pytest.mark.parametrize("randomize_bn", [False, True])
 def test_executing_the_reference_graph_gives_the_oracle_tower(graph, randomize_bn):
     """The reference model is 10 blocks x 256 filters: run it at that size (two boards)."""
-    torch.set_num_threads(4)
     w = tower_oracle.init_weights(10, 256, seed=5, randomize_bn=randomize_bn)
     rng = np.random.default_rng(9)
     w["policy.dense.bias"] = rng.normal(0, 0.1, 1968).astype(np.float32)
