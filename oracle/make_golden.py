@@ -23,6 +23,22 @@ Run in the authoring container only (needs /root/reference):
                       game (halfmove clock > 100 plies deep into the ring) and 800-simulation
                       trees (the AlphaZero budget BASELINE.json's metric is quoted on).
 
+* mcts_noise_cases.json -- ``search_move(noise=True)`` after ``np.random.seed(s)``: the noisy
+                      policy bit for bit and the move it selects.
+* selfplay_games.json -- whole games by the reference's own ``selfplay.play_game`` ->
+                      ``AgentDistributed.best_move / predict_policy / predict_outcome`` ->
+                      ``SelfPlayTree`` -> ``get_game_state`` (functions taken out of the parsed files by
+                      oracle/ref_loader.py because their modules import TensorFlow / python-chess).
+* encoder_cases.json -- ``netencoder.get_game_state`` (+ helpers) over an adapter of the four
+                      python-chess Board / SquareSet members it uses.
+* dataset_cases.json, sequence_cases.json -- ``dataset.DatasetGame`` (imported) and
+                      ``netencoder.DataGameSequence`` (class statement executed) on two of those games.
+* game_agent_cases.json -- ``gameagent.GameAgent`` (class statement executed) against a scripted human.
+* model_graph.json -- the layers ``ChessModel.__init__`` / ``__res_block`` build, recorded by executing
+                      them over stand-ins of the Keras constructors (topology only, no arithmetic).
+
+What is NOT the reference's in these runs: the chess rules (the C oracle stands in for python-chess),
+FakeNet (stands in for the Keras model's numbers) and the adapters named above.
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 """
 import hashlib

@@ -10,8 +10,12 @@ Flatten -> Dense(256) ReLU -> Dense(1) tanh.  BatchNormalization eps = 1e-3,
 moving statistics at inference.
 
 PARITY STATUS: TensorFlow is absent from this image and the reference ships no
-weights, so this restatement is "parity unpinned" against Keras itself; it is
-the fp32 reference the fp16 MFMA tower is held to (|diff| <= 1e-3).
+weights, so the NUMERICS of this restatement are "parity unpinned" against Keras
+itself; its TOPOLOGY is pinned: tests/golden/model_graph.json is the layer graph
+the reference's own constructor builds (recorded by oracle/ref_loader.
+record_model_graph), and tests/test_model_graph.py executes that graph with these
+weights and gets this module's outputs.  It is the fp32 reference the fp16 MFMA
+tower is held to (|diff| <= 1e-3).
 
 Weights live in a flat dict of numpy arrays in Keras layouts (conv HWIO, dense
 (in,out)), generated with Keras-default initialisers (Glorot-uniform kernels,
