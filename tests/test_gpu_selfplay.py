@@ -38,6 +38,37 @@ def test_full_games_with_refill_match_oracle():
     run.close()
 
 
+def test_complete_games_with_the_real_tower_do_not_depend_on_the_policy_format():
+    """48 complete games (refill, compaction of the thinning batch, noise on) with the fused HIP
+    tower: once with the heads writing only the legal moves' probabilities (CRL_POLICY_LEGAL, the
+    default) and once through full 1968-vectors -- the same records, move for move."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+
+    class FullVectorsOnly(object):                       # the same evaluator without the legal-label entry point
+        accepts_bitplanes = True
+
+        def __init__(self, model):
+            self.model = model
+            self.forward_into = model.forward_into
+
+        def __call__(self, planes):
+            return self.model(planes)
+
+    model = ChessModel(blocks=2, filters=64, seed=4)
+    recs = []
+    for ev in (model, FullVectorsOnly(model)):
+        run = SelfPlayRunner(ev, n_parallel=16, sims=12, seed=9, noise=True, total_games=48, max_plies=2048)
+        assert run.engine.legal_priors == (ev is model)
+        recs.append({r.game_id: r for r in run.run()})
+        run.close()
+    a, b = recs
+    assert sorted(a) == sorted(b) == list(range(48))
+    for k in a:
+        assert a[k] == b[k], k
+    assert len({len(r.moves) for r in a.values()}) > 10          # games of many different lengths
+
+
 def test_two_rank_sharding_plays_the_same_games():
     """game id -> rank id % world: two 'ranks' run one after the other on this GPU must
     produce exactly the games a single rank produces (streams keyed by global game id)."""
