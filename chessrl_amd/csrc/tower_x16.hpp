@@ -76,8 +76,9 @@ struct Geo16 {
 };
 
 // stage weight tile t (global format [F out][KT in]) into ring slot t & 3 as the plane image above.
-// (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5: timing-only builds without the weight staging, without
-// the per-tile barrier, without both -- harness diagnostics, WRONG results, never dispatched.)
+// (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5, 6: timing-only builds without the weight staging, without
+// the per-tile barrier, without both, without the fragment reads from LDS -- harness diagnostics, WRONG
+// results, never dispatched.)
 // ALT = 0: every wave moves GL pieces of 1 KiB.  ALT = 1: the tile is moved by ONE half of the
 // workgroup -- waves 0-3 move even tiles, waves 4-7 odd tiles, 2 GL pieces each -- so that of the
 // two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
@@ -312,11 +313,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             const int t_tap0 = t;
             auto fetch_xa = [&](auto IC, bool next_tap) {
                 constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 6) { if (t > 1) return; }       // timing only: no fragment reads
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xa[pt] = lds_read16_asm<i * 64>(ab[next_tap ? 1 : 0][pt]);
             };
             auto fetch_xb = [&](auto IC) {
                 constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 6) { if (t > 1) return; }
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
             };
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             }
             auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
                 constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 6) { if (t > 1) return; }
                 static_for<0, CT>([&](auto CC) {
                     constexpr int ct = decltype(CC)::value;
                     constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (PAIR ? 0 : (i / G::SPT) * G::TILE_BYTES);

@@ -144,6 +144,7 @@ int main(int argc, char **argv)
         stamps<128, 4, 1>(b, 10, boards);
         run("  x16<128,4> no staging (timing)", k_trunk_x16<128, 4, 1, 3>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("  x16<128,4> no barrier (timing)", k_trunk_x16<128, 4, 1, 4>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
+        run("  x16<128,4> no fragment reads (timing)", k_trunk_x16<128, 4, 1, 6>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("  x16<128,4> neither (timing)", k_trunk_x16<128, 4, 1, 5>, Geo16<128, 4>::LDS_BYTES, 4, 128, 10, boards, reps, b, out, &ref);
         run("k_trunk_x16<128,2,1> 512 boards", k_trunk_x16<128, 2, 1>, Geo16<128, 2>::LDS_BYTES, 2, 128, 10, 512, reps, b, out, nullptr);
     }
