@@ -336,6 +336,7 @@ def main():
     t1 = time.perf_counter()
     barrier()
     c1 = run.engine.ctx.counters()
+    moves1 = run.moves_played                 # (the phase profile below crosses a move boundary of its own)
     dt = t1 - t0
     sims = c1["sims"] - c0["sims"]          # simulations completed (backed up) in the timed region
     # the two reductions of the result travel on the process group's own device type
@@ -427,7 +428,7 @@ def main():
                        "tower_precision": getattr(model, "precision", a.dtype),
                        "parallelism": "games sharded, no collective on the hot path"},
             "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,
-                       "move_boundaries_inside": (run.moves_played - moves0) // max(1, G),
+                       "move_boundaries_inside": (moves1 - moves0) // max(1, G),
                        "note": "a window shorter than one move is centred mid-move"},
             "moves_per_sec": total_sims / max_dt / a.sims,
             # games/hour: a random-init 10x128 net at 800 sims/move plays 165.5 moves (331 plies) per
