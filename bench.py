@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-GAME_LENGTH_C3 = 165.5      # moves per game, 512 complete games: profiles/r01/game_length_c3net_800sims.json
+GAME_LENGTH_C3 = 160.04     # moves per game, 4096 complete games: profiles/r02/finite_run_c3_4096_games.json
 
 
 def parse():
@@ -431,7 +431,7 @@ def main():
                        "move_boundaries_inside": (moves1 - moves0) // max(1, G),
                        "note": "a window shorter than one move is centred mid-move"},
             "moves_per_sec": total_sims / max_dt / a.sims,
-            # games/hour: a random-init 10x128 net at 800 sims/move plays 165.5 moves (331 plies) per
+            # games/hour: a random-init 10x128 net at 800 sims/move plays 160.04 moves (320 plies) per
             # game on average (512 complete games, profiles/r01/game_length_c3net_800sims.json);
             # steady state with refill = moves/s / moves per game.  Only stated for that config.
             "self_play_games_per_hour_est": (total_sims / max_dt / a.sims / GAME_LENGTH_C3 * 3600.0
