@@ -432,7 +432,7 @@ def main():
                        "note": "a window shorter than one move is centred mid-move"},
             "moves_per_sec": total_sims / max_dt / a.sims,
             # games/hour: a random-init 10x128 net at 800 sims/move plays 160.04 moves (320 plies) per
-            # game on average (512 complete games, profiles/r01/game_length_c3net_800sims.json);
+            # game on average (4096 complete games, profiles/r02/finite_run_c3_4096_games.json);
             # steady state with refill = moves/s / moves per game.  Only stated for that config.
             "self_play_games_per_hour_est": (total_sims / max_dt / a.sims / GAME_LENGTH_C3 * 3600.0
                                              if (a.sims, B, F) == (800, 10, 128) else None),
