@@ -14,8 +14,9 @@
 //   * fragment lanes: lane l = 16 q + r reads row r of its block, 16-byte quarter q of the 64-byte
 //     K block.  Activation rows are padded to (2 mod 16) 16-byte units (288 / 544 bytes): the 16
 //     lanes of a ds_read_b128 group -- 8 rows at quarter q, 8 at q+1 -- then cover all 64 banks;
-//   * weight tiles keep their global format ([F out][KT in] rows); the 32-channel tiles of the
-//     256-filter tower use the chunk swizzle (-(row >> 2)) & 3 in LDS;
+//   * a weight tile is one 64-byte-row plane per 32 input channels, rows in the order the
+//     accumulators want them (Geo16::row_channel), chunk swizzle (-(row >> 2)) & 3; the host packs
+//     the global image in exactly that order, so the DMA source is contiguous;
 //   * the accumulator of block (pt, ct) holds, per lane, 4 consecutive channels of position
 //     16 pt + r; channel blocks 2g and 2g+1 are interleaved (Geo16::chan_of) so that a lane's 4 + 4
 //     values are 8 consecutive channels and the epilogue writes 16-byte words in place;
@@ -60,22 +61,24 @@ struct Geo16 {
     // the wave's first channel: blocks 2g and 2g+1 interleave in units of 4, so that a lane's 4 + 4
     // values of the two blocks are 8 CONSECUTIVE channels 32 g + 8 q .. + 8 and the epilogue writes
     // them as one 16-byte word (half the LDS write instructions, and conflict-free like the reads:
-    // same (row, 16-byte quarter) lane map).  The permutation is applied where weight rows enter
-    // LDS (source row of the DMA); the global weight image keeps its natural channel order.
+    // same (row, 16-byte quarter) lane map).  The permutation lives in the weight image (row_channel).
     __host__ __device__ static constexpr int chan_of(int ct, int i)
     {
         return 32 * (ct >> 1) + 8 * (i >> 2) + 4 * (ct & 1) + (i & 3);
     }
-    // LDS weight-image row (16 ct + i within a wave's 16 CT rows) -> global row holding its channel
-    __device__ static int src_row(int row)
+    // Output channel held by row `row` of a weight plane (rows 16 ct + i of a wave's 16 CT rows): the
+    // same bit rotation inside every 32-row block whatever the geometry.  The GLOBAL weight image is
+    // stored in exactly the LDS image's order -- planes of [F rows][64 bytes], rows in this order,
+    // the four 16-byte chunks of a row at position chunk ^ wswz(row) (chessrl_amd/model.py:_pack_fused,
+    // include/chessrl_hip.h) -- so a tile is one contiguous block that every wave copies in 1-KiB
+    // pieces (sixteen 64-byte half lines per piece before: -0.8 % / -1.9 % at 128 / 256 filters).
+    __host__ __device__ static constexpr int row_channel(int row)
     {
-        constexpr int W = 16 * CT;
-        const int in = row & (W - 1);
-        return (row & ~(W - 1)) + chan_of(in >> 4, in & 15);
+        return (row & ~31) + chan_of((row >> 4) & 1, row & 15);
     }
 };
 
-// stage weight tile t (global format [F out][KT in]) into ring slot t & 3 as the plane image above.
+// stage weight tile t (global image = the plane image above, contiguous) into ring slot t & 3.
 // (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5, 6: timing-only builds without the weight staging, without
 // the per-tile barrier, without both, without the fragment reads from LDS -- harness diagnostics, WRONG
 // results, never dispatched.)
@@ -94,11 +97,8 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
         const int dst0 = slot0 + (wave_u & 3) * 1024;   // uniform
 #pragma unroll
         for (int j = 0; j < 2 * G::GL; j++) {
-            const int idx = j * 256 + (tid & 255);      // 16-byte slot of the LDS image
-            const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
-            const int row = rem >> 2, phys = rem & 3;
-            const int chunk = phys ^ G::wswz(row);
-            const unsigned off = (unsigned)(G::src_row(row) * G::WROW + ksub * 64 + chunk * 16);
+            const int idx = j * 256 + (tid & 255);      // 16-byte slot of the tile image (global = LDS order)
+            const unsigned off = (unsigned)(idx * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src + off),
                 (__attribute__((address_space(3))) void *)(lds + dst0 + j * 4096), 16, 0, 0);
@@ -107,11 +107,8 @@ __device__ inline void stage_wtile_x16(const unsigned char *wts, lds_byte *lds, 
         const int dst0 = slot0 + wave_u * 1024;         // uniform
 #pragma unroll
         for (int j = 0; j < G::GL; j++) {
-            const int idx = j * 512 + tid;              // 16-byte slot of the LDS image
-            const int ksub = idx / (G::WPLANE / 16), rem = idx % (G::WPLANE / 16);
-            const int row = rem >> 2, phys = rem & 3;
-            const int chunk = phys ^ G::wswz(row);
-            const unsigned off = (unsigned)(G::src_row(row) * G::WROW + ksub * 64 + chunk * 16);
+            const int idx = j * 512 + tid;              // 16-byte slot of the tile image (global = LDS order)
+            const unsigned off = (unsigned)(idx * 16);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(src + off),
                 (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
@@ -164,7 +161,8 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 }
 
 //   planes  fp16 [n_boards][64][128], or 128 plane bitboards per board (BITS)
-//   wts     fp16 tiles, consumption order [conv][tap][in-ch/KT][F out][KT in]
+//   wts     fp16 weight planes in consumption order [conv][tap][in-ch/32][F rows][4 chunks][8 in],
+//           rows and chunks in the LDS image's order (Geo16::row_channel, wswz)
 //   bias    f32 [n_convs][F];  head_w f32 [3][F];  head_b f32 [3]
 //   out     f32 [n_boards][64][F] or nullptr;  head_out f32 [n_boards][192] or nullptr
 // PAIR = 1 (128 and 256 filters): ONE barrier per TWO weight tiles over a ring of five slots.  The

@@ -202,11 +202,25 @@ class ChessModel(object):
         if self.fused:
             self._pack_fused(weights)
 
+    @staticmethod
+    def _plane_order(F_):
+        """(row -> output channel, row -> chunk swizzle) of a weight plane as the trunk kernel keeps
+        it in LDS (csrc/tower_x16.hpp: Geo16::row_channel, wswz)."""
+        rows = np.arange(F_)
+        ct, i = (rows >> 4) & 1, rows & 15
+        chan = (rows & ~31) + 8 * (i >> 2) + 4 * ct + (i & 3)
+        return chan, (-(rows >> 2)) & 3
+
     def _pack_fused(self, w):
-        """BN-folded fp16 kernels as tiles in the kernel's consumption order
-        [conv][tap=ky*3+kx][in-ch/KT][F out][KT in] with KT = 64 (F = 64, 128) or 32 (F = 256);
-        biases f32 [conv][F]."""
-        F_, kt = self.filters, (32 if self.filters == 256 else 64)
+        """BN-folded fp16 kernels as the planes the fused trunk consumes, in consumption order
+        [conv][tap=ky*3+kx][in-ch/32][F rows][4 chunks][8 in]: row r holds output channel
+        _plane_order(F)[0][r], its four 16-byte chunks (8 input channels each) sit at position
+        chunk ^ swizzle(r) -- byte for byte the image the kernel wants in LDS, so its weight DMA
+        copies contiguous blocks.  Biases f32 [conv][F]."""
+        F_ = self.filters
+        chan, swz = self._plane_order(F_)
+        chan_t = torch.from_numpy(chan)
+        src_chunk = torch.from_numpy(np.arange(4)[None, :] ^ swz[:, None])        # [row][phys] -> chunk
         names = [("stem", None)]
         for i in range(self.blocks):
             names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
@@ -218,7 +232,11 @@ class ChessModel(object):
                 kp[:, :k.shape[1]] = k
                 k = kp
             cin = k.shape[1]                                   # 128 for the stem, F otherwise
-            t = k.permute(2, 3, 0, 1).reshape(9, F_, cin // kt, kt).permute(0, 2, 1, 3)   # [tap][kc][o][c]
+            t = k.permute(2, 3, 0, 1).reshape(9, F_, cin // 32, 4, 8)                    # [tap][o][g][chunk][8]
+            t = t[:, chan_t]                                                              # rows in plane order
+            t = t.permute(0, 2, 1, 3, 4)                                                  # [tap][g][row][chunk][8]
+            idx = src_chunk.view(1, 1, F_, 4, 1).expand(9, cin // 32, F_, 4, 8)
+            t = torch.gather(t, 3, idx)                                                   # chunk ^ swizzle(row)
             tiles.append(t.contiguous().reshape(-1))
             biases.append(b)
         kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][F][1][1]

@@ -183,8 +183,12 @@ int  crl_counters(crl_ctx *ctx, uint64_t *out6);
 /* Residual trunk of ChessModel (model.py:33-37,111-122: stem conv + n_blocks residual blocks,
  * BatchNorm folded) for 128 filters as ONE fused MFMA kernel, plus the three 1x1 head
  * convolutions with their BN + ReLU (model.py:40-42,51-55).  fp16 NHWC planes
- * [n_boards][8][8][128] in.  dev_wtiles_f16 holds the folded fp16 kernels as 16-KiB tiles in
- * consumption order [conv][tap][in-ch/64][128 out][64 in]; dev_bias_f32 is [1+2*n_blocks][128].
+ * [n_boards][8][8][128] in.  dev_wtiles_f16 holds the folded fp16 kernels as 64-byte-row planes in
+ * consumption order [conv][tap = ky*3+kx][in-ch/32][128 rows][4 chunks][8 in] -- byte for byte the
+ * image the kernel keeps in LDS, so that its weight DMA copies contiguous 16-KiB blocks: row r of a
+ * plane holds output channel (r & ~31) + 8*((r & 15) >> 2) + 4*((r >> 4) & 1) + (r & 3), and the
+ * 16-byte chunk with input channels 8c .. 8c+7 of that row sits at position c ^ ((-(r >> 2)) & 3)
+ * (chessrl_amd/model.py:_pack_fused is the reference packer); dev_bias_f32 is [1+2*n_blocks][128].
  * Outputs (either may be NULL): dev_out_f32 = fp32 trunk activations [n_boards][8][8][128];
  * dev_head_out_f32 = [n_boards][192] floats after ReLU: [0,128) the policy head in Keras Flatten
  * order (position*2 + channel), [128,192) the value head; from dev_head_w_f32 [3][128] and
@@ -195,10 +199,9 @@ int  crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const vo
                           const void *dev_head_w_f32, const void *dev_head_b_f32,
                           void *dev_head_out_f32);
 /* The same for `filters` in {64, 128, 256} (BASELINE configs C2, C3/C4, C5; 256 is the
- * reference's own width, model.py:33).  Tiles are [filters out][KT in] with KT = 64 (64 and 128
- * filters: 8 / 16 KiB) or 32 (256 filters: 16 KiB), consumption order [conv][tap][in-ch/KT]; the
- * stem has 128 input channels, every
- * other conv `filters`.  Biases [1+2*n_blocks][filters], head weights [3][filters], trunk output
+ * reference's own width, model.py:33).  The weight image is the same sequence of planes
+ * [conv][tap][in-ch/32][filters rows][4 chunks][8 in] with the row and chunk order given above
+ * (the row rule repeats every 32 rows); the stem has 128 input channels, every other conv `filters`.  Biases [1+2*n_blocks][filters], head weights [3][filters], trunk output
  * [n_boards][8][8][filters]. */
 int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
                        const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,

@@ -1,7 +1,9 @@
 """Scratch (GPU): time the 128-filter trunk at the C3 shape.  `python tools/trunk_bench.py [variant]`
 loads the TUNING library (libchessrl_hip_tuning.so, built here with -DCRL_TUNING on first use) and
 runs CRL_TRUNK_VARIANT=variant (0 = production; the ladder of profiles/r01/pmc_trunk_kernel.md;
-timing-only variants give wrong results).  One variant per process: the library reads it once."""
+timing-only variants give wrong results; so do all 32x32x16 variants since the weight image moved to
+the x16 kernels' plane order -- this tool reports time only).  One variant per process: the library
+reads it once."""
 import os
 import sys
 os.environ["CRL_TUNING_LIB"] = "1"

@@ -17,7 +17,7 @@ typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float
                        const float *, const float *, float *);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-struct Bufs { unsigned char *planes, *wts; float *bias, *head_w, *head_b, *head_out; };
+struct Bufs { unsigned char *planes, *wts, *wts16; float *bias, *head_w, *head_b, *head_out; };   // wts: round-1 tile order (32x32x16 kernels); wts16: plane order (x16)
 
 static uint32_t rng_state = 12345;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
@@ -25,11 +25,12 @@ static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return r
 static double run(const char *name, kern_t k, int lds, int boards_per_wg, int F, int blocks, int boards, int reps,
                   const Bufs &b, std::vector<float> &out, const std::vector<float> *ref)
 {
+    const unsigned char *wsel = strstr(name, "x16") ? b.wts16 : b.wts;     // each kernel family reads its own image
     if (const char *only = getenv("ONLY")) {              // profiling: run just the kernels whose label matches
         if (!strstr(name, only)) return 0;
         CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         for (int i = 0; i < 3; i++)
-            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, wsel, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
         CK(hipDeviceSynchronize());
         printf("ran %s x3\n", name);
         return 0;
@@ -43,11 +44,11 @@ static double run(const char *name, kern_t k, int lds, int boards_per_wg, int F,
     double best = 1e9;
     for (int round = 0; round < 3; round++) {
         for (int i = 0; i < 2; i++)
-            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, wsel, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         for (int i = 0; i < reps; i++)
-            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, b.wts, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
+            hipLaunchKernelGGL(k, dim3(boards / boards_per_wg), dim3(512), lds, 0, b.planes, wsel, b.bias, nullptr, blocks, b.head_w, b.head_b, b.head_out);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms / reps < best) best = ms / reps;
@@ -88,6 +89,21 @@ static Bufs make(int F, int blocks, int boards)
     for (auto &x : hb) x = 0.1f;
     CK(hipMalloc(&b.planes, planes.size() * 8)); CK(hipMemcpy(b.planes, planes.data(), planes.size() * 8, hipMemcpyHostToDevice));
     CK(hipMalloc(&b.wts, wbytes)); CK(hipMemcpy(b.wts, w.data(), wbytes, hipMemcpyHostToDevice));
+    {   // the same weights as the x16 kernels' planes: [tile][sub-step][row][4 chunks][8], rows and chunks in LDS order
+        const int KT = F == 256 ? 32 : 64, SPT = KT / 32;
+        const size_t n_tiles = wbytes / 2 / ((size_t)F * KT);
+        std::vector<_Float16> p(wbytes / 2);
+        for (size_t t = 0; t < n_tiles; t++)
+            for (int ks = 0; ks < SPT; ks++)
+                for (int r = 0; r < F; r++) {
+                    const int ch = Geo16<128, 4>::row_channel(r), sw = (0 - (r >> 2)) & 3;
+                    for (int ph = 0; ph < 4; ph++)
+                        for (int e = 0; e < 8; e++)
+                            p[((t * SPT + ks) * F + r) * 32 + ph * 8 + e] =
+                                w[(t * F + ch) * KT + ks * 32 + (ph ^ sw) * 8 + e];
+                }
+        CK(hipMalloc(&b.wts16, wbytes)); CK(hipMemcpy(b.wts16, p.data(), wbytes, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc(&b.bias, bias.size() * 4)); CK(hipMemcpy(b.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&b.head_w, hw.size() * 4)); CK(hipMemcpy(b.head_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&b.head_b, 12)); CK(hipMemcpy(b.head_b, hb.data(), 12, hipMemcpyHostToDevice));
@@ -106,7 +122,7 @@ static void stamps(const Bufs &b, int blocks, int boards)
     const int nwg = boards / NB;
     unsigned long long *dbg; CK(hipMalloc(&dbg, (size_t)nwg * 8 * 6 * 8));
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, 0, b.planes, b.wts, b.bias, (float *)dbg, blocks, b.head_w, b.head_b, b.head_out);
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, 0, b.planes, b.wts16, b.bias, (float *)dbg, blocks, b.head_w, b.head_b, b.head_out);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)nwg * 48);
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
