@@ -242,3 +242,39 @@ def test_dense_head_weight_packing_is_the_fragment_order_the_kernel_reads():
                 hi, lo = packed[t, s, 0, lane], packed[t, s, 1, lane]
                 assert torch.equal(hi, want.half().float())
                 assert (hi + lo - want).abs().max() <= want.abs().max() * 2.0 ** -21
+
+
+def test_trunk_weight_image_is_the_plane_order_the_header_documents():
+    """ChessModel._pack_fused (CPU tensors, no GPU): the fp16 image handed to crl_trunk_forward is
+    [conv][tap][in-ch/32][F rows][4 chunks][8 in] with row r holding output channel
+    (r & ~31) + 8*((r & 15) >> 2) + 4*((r >> 4) & 1) + (r & 3) and input channels 8c..8c+7 at chunk
+    position c ^ ((-(r >> 2)) & 3) (include/chessrl_hip.h) -- checked element by element against the
+    BatchNorm-folded kernels, stem (128 input planes incl. the zero pad) and residual convs."""
+    import torch
+    from chessrl_amd import model as M
+    from oracle import tower_oracle
+    F_, blocks = 64, 1
+    w = tower_oracle.init_weights(blocks, F_, seed=3, randomize_bn=True)
+    m = M.ChessModel.__new__(M.ChessModel)
+    m.filters, m.blocks, m.device = F_, blocks, torch.device("cpu")
+    m._pack_fused(w)
+    img = m._wtiles.float().numpy()
+    assert m._wtiles.dtype == torch.float16
+    convs = [("stem", None), ("block0.conv1", "block0.bn1"), ("block0.conv2", "block0.bn2")]
+    assert img.size == 9 * 128 * F_ + 2 * 9 * F_ * F_
+    rng = np.random.default_rng(0)
+    off = 0
+    for conv, bn in convs:
+        k, _ = M._fold(w, conv, bn)                                  # [O][I][ky][kx] fp32
+        k = k.half().float().numpy()
+        cin = 128 if conv == "stem" else F_
+        planes = img[off:off + 9 * cin * F_].reshape(9, cin // 32, F_, 4, 8)
+        for _ in range(400):
+            tap, g, r, c, e = (int(rng.integers(n)) for n in (9, cin // 32, F_, 4, 8))
+            chan = (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3)
+            pos = c ^ ((-(r >> 2)) & 3)
+            i = 32 * g + 8 * c + e
+            want = k[chan, i, tap // 3, tap % 3] if i < k.shape[1] else 0.0    # stem: plane 127 is a zero pad
+            assert planes[tap, g, r, pos, e] == want, (conv, tap, g, r, c, e)
+        off += 9 * cin * F_
+    assert sorted({(r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3) for r in range(F_)}) == list(range(F_))
