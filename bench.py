@@ -14,7 +14,10 @@ boundaries (fresh tree, root priors, host compute_policy, two pushes) included w
 game's budget of simulations completes.  ``value`` = simulations completed by all ranks / wall
 time of the K timed steps (max over ranks), state resident in HBM throughout.  When K is
 shorter than one move the window is placed mid-move (the trees are pre-grown un-timed), so a
-short run sees trees of representative depth instead of 800 root expansions.
+short run sees trees of representative depth instead of 800 root expansions; such a window holds
+no move boundary, so one boundary (end_move + begin_move of a full-length move) is timed right
+after it and the line carries ``move_boundary`` and ``value_incl_boundaries`` = G x S / (S x
+ms_per_step + boundary ms), the rate a run of whole moves sustains.
 
 Workload (BASELINE.json metric "MCTS simulations/sec at 800 sims/move", config C3 -- fits one
 GPU): 4096 games in lockstep per GPU, 800 sims/move, 10-block/128-filter random-init tower,
@@ -38,6 +41,12 @@ import socket
 import subprocess
 import sys
 import time
+
+# The pool's host driver only supports dmabuf IPC: without this RCCL (and any CUDA-tensor sharing
+# between processes) fails with "hipIpcGetMemHandle: invalid argument".  The image exports it; it
+# is set here as well, before anything initialises HSA, so that the launcher path (torchrun) and the
+# self-spawn path (--gpus N by hand) run their ranks in the same environment.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
@@ -65,16 +74,42 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="PyTorch-ROCm trunk instead of the HIP kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
+                   help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
 
 
 # ---- launching the ranks -------------------------------------------------------------------------
+def visible_gpus():
+    """Number of GPUs the ranks will see, WITHOUT initialising HIP/HSA in this process (the launcher
+    parent must not touch the GPU: it only starts children): the KFD topology nodes that have SIMDs,
+    narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None when /sys has no KFD."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = sorted(os.listdir(base), key=int)
+    except (OSError, ValueError):
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if line.strip())
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n):
-    """``--gpus n`` without a launcher: start n rank processes of this script (children, started
-    before this process has made any GPU call) and return the worst exit status."""
+    """``--gpus n`` without a launcher: start n rank processes of this script (ordinary children;
+    this parent makes no GPU call at all, before or after) and return the worst exit status."""
     if "CRL_BENCH_DEVICE" not in os.environ and os.environ.get("CRL_BENCH_DRYRUN") != "1":
-        have = torch.cuda.device_count()                   # counting devices does not initialise one
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
             return 2
     with socket.socket() as s:
@@ -83,7 +118,7 @@ def spawn_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -133,7 +168,9 @@ def init_ranks(a):
         local = int(os.environ["CRL_BENCH_DEVICE"])
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
-    if world == 1:
+    # CRL_BENCH_FORCE_GROUP=1 (self-test on a 1-GPU box): a world of one still creates the process
+    # group, so the RCCL branch below, the reductions and the record gather execute on hardware
+    if world == 1 and os.environ.get("CRL_BENCH_FORCE_GROUP") != "1":
         return rank, world, local, None
     import torch.distributed as dist
     backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
@@ -175,9 +212,10 @@ def profile_phases(run, n):
     """HIP-event time of each phase of a step, measured eagerly (no graph) on `n` real steps in
     the middle of a move, on the stream the kernels are launched on."""
     eng = run.engine
-    if run._sims_in_move is not None:
+    if run._sims_in_move:                       # mid-move: finish it first
         run.end_move()
-    run.begin_move()
+    if run._sims_in_move is None:
+        run.begin_move()
     for _ in range(max(0, run.sims // 2 - n)):
         eng.step()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
@@ -211,10 +249,38 @@ def pmc_traffic(kernel, shape):
 
 
 def trunk_kernel_name(F, G, bits):
-    """The dispatch rule of crl_trunk_forward (csrc/api.hip), as rocprofv3 prints the kernel."""
-    small = G <= 128 * (2 if F == 256 else 4)
-    nb = {64: (2 if small else 4), 128: (2 if small else 4), 256: (1 if small else 2)}[F]
-    return "k_trunk_x16<%d, %d, %d>" % (F, nb, bits)
+    """The kernel crl_trunk_forward dispatches for this shape, asked of the library itself
+    (crl_trunk_kernel_name), as rocprofv3 prints it."""
+    import ctypes
+    from chessrl_amd import _lib
+    buf = ctypes.create_string_buffer(128)
+    rc = _lib.lib().crl_trunk_kernel_name(F, G, int(bits), buf, len(buf))
+    if rc != 0:
+        raise RuntimeError("crl_trunk_kernel_name failed (%d)" % rc)
+    return buf.value.decode()
+
+
+def time_move_boundary(run):
+    """One move boundary as a full-length move ends it: the last backprop, D2H of the root statistics,
+    host compute_policy + argmax, the two pushes, harvest/refill (end_move) and the next move's fresh
+    trees + root evaluation (begin_move).  The rest of the current move is played un-timed first.
+    Host clock between two device synchronisations: the GPU is idle while the host works."""
+    if run._sims_in_move is None:
+        run.begin_move()
+    while run._sims_in_move < run.sims:
+        run.engine.step()
+        run._sims_in_move += 1
+        if run._sims_in_move == max(1, run.sims // 2):
+            run._draw_noise_ahead()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.end_move()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run.begin_move()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return {"end_move_ms": (t1 - t0) * 1e3, "begin_move_ms": (t2 - t1) * 1e3, "ms": (t2 - t0) * 1e3}
 
 
 def cpu_baseline(seconds):
@@ -255,7 +321,7 @@ def time_record_gather(run, dist, max_plies):
     best = None
     for _ in range(3):
         st = {}
-        rows, counts = records.gather_blocks(block, stats=st)
+        rows, counts = records.gather_blocks(block, stats=st, force_collective=True)
         if best is None or st["ms"] < best["ms"]:
             best = st
         dist.barrier()
@@ -311,11 +377,12 @@ def main():
                        seed=a.seed, fused=not a.no_fused)
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
-                         device=local, use_graph=not a.no_graph, max_plies=max_plies)
+                         device=local, use_graph=not a.no_graph, max_plies=max_plies,
+                         numpy_promotion=a.numpy_promotion)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -340,9 +407,9 @@ def main():
     dt = t1 - t0
     sims = c1["sims"] - c0["sims"]          # simulations completed (backed up) in the timed region
     # the two reductions of the result travel on the process group's own device type
-    rdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    rdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
     tot = torch.tensor([float(sims), dt], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if dist is not None:
         s = tot.clone()
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         m = tot.clone()
@@ -350,7 +417,7 @@ def main():
         total_sims, max_dt = s[0].item(), m[1].item()
     else:
         total_sims, max_dt = float(sims), dt
-    gather = time_record_gather(run, dist, max_plies) if world > 1 else None
+    gather = time_record_gather(run, dist, max_plies) if dist is not None else None
 
     if rank == 0:
         G, F, B = a.games, a.filters, a.blocks
@@ -400,7 +467,14 @@ def main():
         # other evaluator gets 16-KiB fp16 planes.  With the HIP heads only the legal moves' priors
         # exist (2 x b x (2 B label + 4 B prior written + 4 B read)); else full policy vectors
         plane_bytes = 1024.0 if eng.bitplanes else 16384.0      # per evaluated position (S1 and S2)
-        tree_bytes = 2400.0 + 20.0 * depth * branch + 2 * plane_bytes
+        # select reads one 24-byte edge record per legal move per level (value sum f64, visits i32,
+        # prior f32, move u16, child u16: csrc/state.hpp; SURVEY's 20 B of fields + the move/child ids
+        # the descent needs); the fixed part is SURVEY section 8d's 2.4 KB, of which the policy term
+        # (2 x b x 2 B of logits there) is replaced by what this build really exchanges with the heads
+        policy_bytes = (2 * branch * (2 + 4 + 4) if eng.legal_priors          # label u16 + prior f32 written + read
+                        else 2 * (2 * 1968 * 4 + branch * 4))                  # full fp32 vectors written + read, gathered
+        tree_bytes = (2400.0 - 2 * branch * 2) + 24.0 * depth * branch + policy_bytes + 2 * plane_bytes
+        boundary = time_move_boundary(run)               # rank 0 only; the other ranks wait at the last barrier
         ph = profile_phases(run, 16)
         tree_ms = ph["select_expand"] + ph["reply"]
         t_traffic, t_src = pmc_traffic("k_select_expand + k_reply",
@@ -411,7 +485,20 @@ def main():
                 "frac": tree_bytes * G / tree_ms / 1e6 / HBM_PEAK_GBS,
                 "traffic": t_traffic, "traffic_source": t_src,
                 "launch_ms": tree_ms, "phase_ms": ph, "bytes_per_sim": tree_bytes,
+                "bytes_model": "2.4 KB fixed (SURVEY 8d) + 24 B x depth x branch (edge records) + "
+                               "%s + 2 x %d B planes" % ("2 x branch x 10 B legal labels/priors" if eng.legal_priors
+                                                         else "2 x (2 x 7872 B policy vectors + 4 B x branch)", int(plane_bytes)),
                 "mean_depth": depth, "mean_branch": branch}
+        inside = (moves1 - moves0) // max(1, G)
+        ms_step = max_dt / a.steps * 1e3
+        if boundary is not None:
+            # whole moves at this step rate with the measured boundary: what a run of many moves sustains
+            incl = G * a.sims / ((a.sims * ms_step + boundary["ms"]) * 1e-3) if inside == 0 else total_sims / max_dt
+            boundary["note"] = ("timed separately (the window holds no boundary); value_incl_boundaries = G x S / "
+                                "(S x ms_per_step + boundary ms)" if inside == 0 else
+                                "the window already holds %d boundaries: value_incl_boundaries = value" % inside)
+        else:
+            incl = None
         cfg_name = {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
                     (4096, 800, 20, 256): "C5 per-GPU shard"}.get((G, a.sims, B, F), "custom")
         out = {
@@ -426,15 +513,18 @@ def main():
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
                        "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",
                        "tower_precision": getattr(model, "precision", a.dtype),
+                       "trunk_kernel": kern if model.fused else None,
+                       "numpy_promotion": eng.numpy_promotion,
                        "parallelism": "games sharded, no collective on the hot path"},
             "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,
-                       "move_boundaries_inside": (moves1 - moves0) // max(1, G),
+                       "move_boundaries_inside": inside,
                        "note": "a window shorter than one move is centred mid-move"},
-            "moves_per_sec": total_sims / max_dt / a.sims,
+            "move_boundary": boundary, "value_incl_boundaries": incl,
+            "moves_per_sec": (incl or total_sims / max_dt) / a.sims,
             # games/hour: a random-init 10x128 net at 800 sims/move plays 160.04 moves (320 plies) per
             # game on average (4096 complete games, profiles/r02/finite_run_c3_4096_games.json);
             # steady state with refill = moves/s / moves per game.  Only stated for that config.
-            "self_play_games_per_hour_est": (total_sims / max_dt / a.sims / GAME_LENGTH_C3 * 3600.0
+            "self_play_games_per_hour_est": ((incl or total_sims / max_dt) / a.sims / GAME_LENGTH_C3 * 3600.0
                                              if (a.sims, B, F) == (800, 10, 128) else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
@@ -445,10 +535,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()            # rank 0 is still profiling its phases: nobody tears RCCL down early
     run.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -15,9 +15,6 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 _CSRC = os.path.join(_PKG, "csrc")
 SO_PATH = os.path.join(_PKG, "libchessrl_hip.so")
-# the tuning library (tools/trunk_bench.py): the product plus the first-build and timing-only trunk
-# kernels (-DCRL_TUNING); never built by build()/__graft_entry__ and never loaded by the package
-SO_TUNING_PATH = os.path.join(_PKG, "libchessrl_hip_tuning.so")
 HEADER = os.path.join(_ROOT, "include", "chessrl_hip.h")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -28,8 +25,8 @@ def sources():
     return files + [HEADER]
 
 
-def source_hash(extra=()):
-    h = hashlib.sha256(" ".join(HIPCC_FLAGS + list(extra)).encode())
+def source_hash():
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
     for f in sources():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
@@ -52,7 +49,7 @@ SYMBOLS = [
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
-    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch", "crl_heads_forward",
+    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
     "crl_heads_forward_legal",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
@@ -66,19 +63,25 @@ def _stamp(so):
     return so + ".srchash"
 
 
-def is_stale(so=SO_PATH, extra=()):
-    """True when `so` is missing or was not compiled from the sources as they are now (the build
-    leaves the sources' sha256 next to the library)."""
-    if not (os.path.exists(so) and os.path.exists(_stamp(so))):
+def is_stale(so=SO_PATH):
+    """True when `so` is missing or its stamp says it was compiled from other sources than the
+    ones present (the build leaves the sources' sha256 next to the library).  A library WITHOUT a
+    stamp (a deploy copy that left the untracked ``*.srchash`` behind) is not stale: it is loaded
+    as shipped, see ``lib()``."""
+    if not os.path.exists(so):
         return True
-    return open(_stamp(so)).read().strip() != source_hash(extra)
+    if not os.path.exists(_stamp(so)):
+        return False
+    return open(_stamp(so)).read().strip() != source_hash()
 
 
-def build(force=False, verbose=False, tuning=False):
+def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> chessrl_amd/libchessrl_hip.so (in-tree; works without a GPU).
-    Recompiles whenever any file of csrc/ or the header changed since the library was built."""
-    so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
-    if not force and not is_stale(so, extra):
+    Recompiles whenever any file of csrc/ or the header changed since the library was built, or
+    when the library carries no stamp (``force`` recompiles regardless)."""
+    so = SO_PATH
+    fresh = lambda: os.path.exists(_stamp(so)) and not is_stale(so)
+    if not force and fresh():
         return so
     # several ranks of one node may arrive here together (torchrun starts one process per GPU):
     # one compiles, the others wait on the lock and find the library fresh; the library and its
@@ -86,10 +89,10 @@ def build(force=False, verbose=False, tuning=False):
     import fcntl
     with open(so + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and not is_stale(so, extra):
+        if not force and fresh():
             return so
         tmp = "%s.tmp.%d" % (so, os.getpid())
-        cmd = ["hipcc"] + HIPCC_FLAGS + extra + ["-o", tmp, os.path.join(_CSRC, "api.hip")]
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", tmp, os.path.join(_CSRC, "api.hip")]
         if verbose:
             print(" ".join(cmd))
         try:
@@ -98,7 +101,7 @@ def build(force=False, verbose=False, tuning=False):
                 os.remove(_stamp(so))
             os.replace(tmp, so)
             with open(_stamp(so) + ".tmp", "w") as f:
-                f.write(source_hash(extra) + "\n")
+                f.write(source_hash() + "\n")
             os.replace(_stamp(so) + ".tmp", _stamp(so))
         finally:
             if os.path.exists(tmp):
@@ -110,27 +113,31 @@ _lib = None
 
 
 def lib():
-    """Load the shared library, compiling it first when it is missing or older than its sources
-    (``CRL_TUNING_LIB=1``: the tuning library instead, tools only).  No CPU fallback: without a
-    loadable library this raises."""
+    """Load the shared library.  It is compiled first when it is missing or its stamp shows it is
+    older than csrc/; a library without a stamp, or a stale one on a box without hipcc, is loaded
+    as shipped with a warning.  No CPU fallback: without a loadable library this raises."""
     global _lib
     if _lib is not None:
         return _lib
     # torch bundles its own libamdhip64; it must be the copy this process binds, or the tower and
     # the search kernels would sit on two HIP runtimes (and the second one sees no device)
     import torch  # noqa: F401
-    tuning = os.environ.get("CRL_TUNING_LIB") == "1"
-    so, extra = (SO_TUNING_PATH, ["-DCRL_TUNING"]) if tuning else (SO_PATH, [])
-    override = os.environ.get("CRL_LIB_PATH")          # tools only: A/B an older build of the library
-    if override:
-        so = override
-    elif is_stale(so, extra):
+    so = SO_PATH
+    if is_stale(so):
         try:
-            build(tuning=tuning)
+            build()
         except Exception as e:  # pragma: no cover
-            raise HipLibraryError(
-                "%s is missing or older than csrc/ and could not be rebuilt with hipcc (%s); "
-                "the HIP path has no CPU fallback" % (os.path.basename(so), e))
+            if not os.path.exists(so):
+                raise HipLibraryError(
+                    "%s is missing and could not be built with hipcc (%s); "
+                    "the HIP path has no CPU fallback" % (os.path.basename(so), e))
+            import warnings
+            warnings.warn("%s is older than csrc/ and could not be rebuilt with hipcc (%s): loading it "
+                          "as shipped" % (os.path.basename(so), e))
+    elif not os.path.exists(_stamp(so)):
+        import warnings
+        warnings.warn("%s carries no source stamp (*.srchash was not deployed with it): loading it as "
+                      "shipped, freshness against csrc/ unchecked" % os.path.basename(so))
     try:
         L = ctypes.CDLL(so)
     except OSError as e:
@@ -172,6 +179,7 @@ def lib():
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_trunk_set_small_batch.argtypes = [i32]
+    L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]
     L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.crl_heads_forward_legal.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.crl_set_policy_format.argtypes = [vp, i32]
@@ -283,6 +291,12 @@ class Context(object):
         counts = np.zeros(self.G, dtype=np.int32)
         self._ck(self._L.crl_legal_moves(self._h, _ptr(moves), _ptr(counts)), "crl_legal_moves")
         return moves, counts
+
+    def legal_counts(self):
+        """len(get_legal_moves()) per game without copying the move lists back."""
+        counts = np.zeros(self.G, dtype=np.int32)
+        self._ck(self._L.crl_legal_moves(self._h, None, _ptr(counts)), "crl_legal_moves")
+        return counts
 
     def push_moves(self, moves):
         m = np.ascontiguousarray(moves, dtype=np.uint16)

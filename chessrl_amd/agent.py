@@ -21,7 +21,7 @@ class Agent(Player):
     """``model``: a ``ChessModel`` (or any callable planes -> (policy, value) on the GPU)."""
 
     def __init__(self, color, weights=None, endpoint=None, num_threads=6, model=None,
-                 blocks=10, filters=256, numpy_promotion="nep50"):
+                 blocks=10, filters=256, numpy_promotion="auto"):
         super().__init__(color)
         if model is None:
             from .model import ChessModel

@@ -2,11 +2,6 @@
 // C-ABI declared in include/chessrl_hip.h.  gfx950 only; no torch types cross this boundary.
 #include "../../include/chessrl_hip.h"
 #include "search.hpp"
-#ifdef CRL_TUNING
-#include "tower.hpp"
-#endif
-#include "tower_pipe.hpp"
-#include "tower_gen.hpp"
 #include "tower_x16.hpp"
 #include "heads.hpp"
 #include "train_ops.hpp"
@@ -350,11 +345,12 @@ int crl_get_positions(crl_ctx *ctx, crl_board *boards_out, int n)
 
 int crl_legal_moves(crl_ctx *ctx, uint16_t *moves, int32_t *counts)
 {
-    if (!ctx || !moves || !counts) return fail(ctx, CRL_ERR_ARG, "crl_legal_moves: bad argument");
+    if (!ctx || !counts) return fail(ctx, CRL_ERR_ARG, "crl_legal_moves: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t G = ctx->W;
     LAUNCH(ctx, k_legal_moves, ctx->d, ctx->t_moves, ctx->t_i32b);
-    HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->t_moves, G * MAX_MOVES * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
+    if (moves)
+        HIP_TRY(ctx, hipMemcpyAsync(moves, ctx->t_moves, G * MAX_MOVES * sizeof(u16), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->t_i32b, G * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     return check_dev_error(ctx);
 }
@@ -553,16 +549,6 @@ int crl_trunk_set_small_batch(int enabled)
     return CRL_OK;
 }
 
-#ifdef CRL_TUNING
-// Tuning library only: CRL_TRUNK_VARIANT selects first-build / timing-only builds of the 128-filter
-// kernel (tools/trunk_bench.py; the ladder in profiles/r01/pmc_trunk_kernel.md).  Read once.
-static int tuning_variant()
-{
-    static const int v = [] { const char *e = getenv("CRL_TRUNK_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-#endif
-
 // opt in to > 64 KiB of dynamic LDS once per (device, kernel)
 static hipError_t allow_big_lds(const void *kern, int lds_bytes)
 {
@@ -577,6 +563,13 @@ static hipError_t allow_big_lds(const void *kern, int lds_bytes)
     e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e == hipSuccess) ready.push_back({ dev, kern });
     return e;
+}
+
+// the dispatch rule of the fused trunk, in one place (trunk_forward launches by it and
+// crl_trunk_kernel_name reports it)
+static bool trunk_small_batch(int filters, int n_boards)
+{
+    return n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
 }
 
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, bool bits,
@@ -597,7 +590,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     int lds_bytes = 0, boards_per_wg = 0;
     // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
     // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
-    const bool small = n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
+    const bool small = trunk_small_batch(filters, n_boards);
     // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count; 128 and 256
     // filters with one barrier per two weight tiles over a five-slot ring (PAIR)
     // 64 filters at four boards per workgroup: taps in groups of three over a nine-slot ring (GROUP);
@@ -619,53 +612,6 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         if (small) CRL_X16(128, 2); else CRL_X16(128, 4);
     }
 #undef CRL_X16
-#ifdef CRL_TUNING
-    // tuning library: the 32x32x16 kernels (tower_pipe.hpp / tower_gen.hpp / tower.hpp) by variant
-#define CRL_GEN(F_, NB_)                                                                        \
-    do {                                                                                         \
-        kern = bits ? crl_tower::k_trunk_gen<F_, NB_, 1> : crl_tower::k_trunk_gen<F_, NB_, 0>;   \
-        lds_bytes = crl_tower::Geo<F_, NB_>::LDS_BYTES;                                          \
-        boards_per_wg = NB_;                                                                     \
-    } while (0)
-    if (tuning_variant() == 400) {                       // 32x32x16 production set of round 1
-        if (filters == 256) { if (small) CRL_GEN(256, 1); else CRL_GEN(256, 2); }
-        else if (filters == 64) { if (small) CRL_GEN(64, 2); else CRL_GEN(64, 4); }
-        else if (small) CRL_GEN(128, 2);
-        else {
-            kern = bits ? crl_tower::k_trunk128_pipe<0, 1> : crl_tower::k_trunk128_pipe<0, 0>;
-            lds_bytes = crl_tower::P2_LDS_BYTES;
-            boards_per_wg = crl_tower::BOARDS_PER_WG;
-        }
-    } else if (filters == 128 && !small && !bits && tuning_variant() != 0) {
-        const int first = crl_tower::LDS_BYTES;        // LDS size of the first-build kernels
-        lds_bytes = crl_tower::P2_LDS_BYTES;
-        boards_per_wg = crl_tower::BOARDS_PER_WG;
-        switch (tuning_variant()) {
-        case 10: kern = crl_tower::k_trunk128<0>; lds_bytes = first; break;    // unpipelined baseline
-        case 1: kern = crl_tower::k_trunk128<1>; lds_bytes = first; break;     // + s_setprio
-        case 2: kern = crl_tower::k_trunk128<2>; lds_bytes = first; break;     // all reads up front
-        case 3: kern = crl_tower::k_trunk128<3>; lds_bytes = first; break;     // x reads before barrier
-        case 100: kern = crl_tower::k_trunk128<100>; lds_bytes = first; break; // 100..106 timing only
-        case 101: kern = crl_tower::k_trunk128<101>; lds_bytes = first; break;
-        case 102: kern = crl_tower::k_trunk128<102>; lds_bytes = first; break;
-        case 103: kern = crl_tower::k_trunk128<103>; lds_bytes = first; break;
-        case 104: kern = crl_tower::k_trunk128<104>; lds_bytes = first; break;
-        case 105: kern = crl_tower::k_trunk128<105>; lds_bytes = first; break;
-        case 106: kern = crl_tower::k_trunk128<106>; lds_bytes = first; break;
-        case 200: kern = crl_tower::k_trunk128_pipe<0>; break;                 // round-1 production
-        case 201: kern = crl_tower::k_trunk128_pipe<1>; break;                 // 201..203 timing only
-        case 202: kern = crl_tower::k_trunk128_pipe<2>; break;
-        case 203: kern = crl_tower::k_trunk128_pipe<3>; break;
-        case 204: kern = crl_tower::k_trunk128_pipe<4>; break;                 // staggered staging
-        case 216: kern = crl_tower::k_trunk128_pipe<16>; break;                // x reads for dx = 0 only
-        case 232: kern = crl_tower::k_trunk128_pipe<32>; break;                // no vmcnt wait for the DMA
-        case 234: kern = crl_tower::k_trunk128_pipe<34>; break;                // ... and no barrier
-        case 300: CRL_GEN(128, 4); break;                                      // the template at F = 128
-        default: kern = crl_tower::k_trunk_x16<128, 4, 0>; lds_bytes = crl_tower::Geo16<128, 4>::LDS_BYTES; break;
-        }
-    }
-#undef CRL_GEN
-#endif
     hipError_t ea = allow_big_lds((const void *)kern, lds_bytes);
     if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
     hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),
@@ -676,6 +622,17 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
                        (float *)dev_head_out_f32);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_trunk_kernel_name(int filters, int n_boards, int bitplanes, char *buf, int buf_len)
+{
+    if ((filters != 64 && filters != 128 && filters != 256) || n_boards < 4 || !buf || buf_len < 1)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_kernel_name: bad argument");
+    const bool small = trunk_small_batch(filters, n_boards);
+    const int nb = filters == 256 ? (small ? 1 : 2) : (small ? 2 : 4);
+    const int pair = filters == 64 ? 0 : 1, group = (filters == 64 && nb == 4) ? 1 : 0;
+    snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d>", filters, nb, bitplanes ? 1 : 0, pair, group);
     return CRL_OK;
 }
 
@@ -706,16 +663,9 @@ int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boar
         (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
         return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward: bad argument");
     const unsigned blocks = (unsigned)((n_boards + 15) / 16);
-    // every policy workgroup streams the whole packed kernel from L2: 32 boards per workgroup once
-    // that still leaves every CU a workgroup
-    if (n_boards >= 1 << 30)                 // 32-board workgroups: measured no faster (the launch is latency-, not L2-bound)
-        hipLaunchKernelGGL(crl_heads::k_policy_head<2>, dim3((blocks + 1) / 2), dim3(512), 0, (hipStream_t)hip_stream,
-                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
-                           (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
-    else
-        hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
-                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
-                           (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
+    hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
+                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
+                       (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
     if (dev_value_out_f32)
         hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
                            (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,

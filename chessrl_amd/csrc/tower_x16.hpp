@@ -1,5 +1,5 @@
-// tower_x16.hpp -- the fused residual trunk (design: tower_common.hpp; pipeline: tower_pipe.hpp /
-// tower_gen.hpp) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
+// tower_x16.hpp -- the fused residual trunk (design: tower_common.hpp) on v_mfma_f32_16x16x32_f16
+// (the round-1 kernels on v_mfma_f32_32x32x16_f16 are tools/ubench/r1_kernels/, harness only).
 //
 // Why: the trunk is matrix-pipe bound on a POWER-limited clock.  With the same 64x64 wave tile,
 // the same LDS bytes per MAC and the same 64 accumulator registers, a 16x16x32 loop sustains
@@ -8,7 +8,7 @@
 // cycles per FLOP, higher held clock).  Results are NOT bit-identical to the 32x32x16 kernels:
 // the K = 32 contraction of one instruction sums in a different order (both accumulate fp32).
 //
-// What changes against tower_gen.hpp:
+// What changes against the round-1 32x32x16 kernels:
 //   * a wave tile of MT x NT 32x32 blocks becomes PT x CT = 2MT x 2NT blocks of 16 positions x 16
 //     channels; a sub-step is 32 input channels: PT + CT fragment reads feed PT*CT MFMAs;
 //   * fragment lanes: lane l = 16 q + r reads row r of its block, 16-byte quarter q of the 64-byte
@@ -22,7 +22,7 @@
 //     values are 8 consecutive channels and the epilogue writes 16-byte words in place;
 //   * the head convolutions reduce 4 CG partial sums per output (4 lane quarters x CG waves).
 #pragma once
-#include "tower_gen.hpp"
+#include "tower_common.hpp"
 
 namespace crl_tower {
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                                                        const float *__restrict__ head_b,
                                                        float *__restrict__ head_out)
 {
-#if !defined(CRL_TUNING) && !defined(CRL_HARNESS)
+#if !defined(CRL_HARNESS)
     static_assert(ALT == 0, "diagnostic variants are for tools/ubench/trunk_variants.hip only");
 #endif
     typedef Geo16<F, NB> G;

@@ -82,8 +82,11 @@ class DatasetGame(object):
         """A single game or every game of another dataset."""
         if isinstance(other, DatasetGame):
             self.games.extend(other.games)
-        elif isinstance(other, game_mod.Game):
-            self.games.append(other)
+        elif isinstance(other, game_mod.Game) or callable(getattr(other, "get_history", None)):
+            self.games.append(other)                       # a Game, or a slot-free GameRecord
+        else:
+            raise TypeError("DatasetGame.append: expected a DatasetGame, a Game or a GameRecord, got %s"
+                            % type(other).__name__)
 
     def __add__(self, other):
         self.append(other)

@@ -43,14 +43,27 @@ def compute_policy(visits, root_visits, nb_moves, noise=True, rng=None):
     return policy
 
 
-def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None):
+_ALPHA = {}
+
+
+def dirichlet_row(src, n):
+    """``np.random.dirichlet([0.03] * n)`` (mctree.py:319-320) from the stream ``src``."""
+    a = _ALPHA.get(n)
+    if a is None:
+        a = _ALPHA[n] = np.full(n, 0.03)
+    return src.dirichlet(a)
+
+
+def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None, noise_rows=None):
     """``np.argmax(compute_policy(...))`` for every game at once (-1 where nchild == 0).
 
     Same arithmetic as ``compute_policy`` element for element (numpy's array ``power`` and
     division are the scalar ones applied per element), so the chosen child is identical; only
     the per-game Dirichlet draw stays a loop because every game owns its random stream.
     ``visits`` [G, >=max(nchild)] int, children order; ``rngs`` one generator per game (or None
-    for the global ``np.random`` stream, drawn in game order).
+    for the global ``np.random`` stream, drawn in game order); ``noise_rows``: the draws already
+    made for this move (``SelfPlayRunner`` makes them while the GPU searches), one row of
+    ``nchild[g]`` entries per game with children.
     """
     G = len(nchild)
     nchild = np.asarray(nchild)
@@ -67,13 +80,34 @@ def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None):
         for g in range(G):
             n = int(nchild[g])
             if n:
-                src = rngs[g] if rngs is not None else np.random
-                chosen[g] = int(np.argmax((1 - 0.25) * pol[g, :n] + src.dirichlet([0.03] * n)))
+                if noise_rows is not None:
+                    row = noise_rows[g]
+                    if row is None or len(row) != n:
+                        raise RuntimeError("noise drawn ahead for %s children, game %d has %d"
+                                           % (None if row is None else len(row), g, n))
+                else:
+                    row = dirichlet_row(rngs[g] if rngs is not None else np.random, n)
+                chosen[g] = int(np.argmax((1 - 0.25) * pol[g, :n] + row))
     else:
         live = nchild > 0
         masked = np.where(cols[None, :] < nchild[:, None], pol, -np.inf)
         chosen[live] = np.argmax(masked[live], axis=1)
     return chosen
+
+
+def resolve_numpy_promotion(mode="auto"):
+    """Which arithmetic ``Node.get_value``'s ``C * self.prior`` (mctree.py:79-87: python int x
+    ``np.float32`` scalar) has.  Under the reference's pinned numpy==1.17.2 (requirements.txt:6;
+    any numpy < 2) value-based scalar promotion makes it a float64 product: ``"legacy"``; under
+    numpy >= 2 (NEP 50) it is rounded to float32: ``"nep50"``.  ``"auto"`` (the default
+    everywhere) asks the numpy this process runs on -- the same numpy the reference would run on
+    if it were started in this interpreter, so a drop-in replacement computes what the code it
+    replaces computed there."""
+    if mode == "auto":
+        return "legacy" if (10 * np.float32(0.1)).dtype == np.float64 else "nep50"
+    if mode not in ("nep50", "legacy"):
+        raise ValueError("numpy_promotion must be 'auto', 'nep50' or 'legacy'")
+    return mode
 
 
 class LockstepEngine(object):
@@ -84,11 +118,11 @@ class LockstepEngine(object):
     """
 
     def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
-                 numpy_promotion="nep50", use_graph=True, bitplanes=None, legal_priors=None):
+                 numpy_promotion="auto", use_graph=True, bitplanes=None, legal_priors=None):
+        numpy_promotion = resolve_numpy_promotion(numpy_promotion)
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
-        if numpy_promotion not in ("nep50", "legacy"):
-            raise ValueError("numpy_promotion must be 'nep50' or 'legacy'")
+        self.numpy_promotion = numpy_promotion
         self.G, self.max_sims = n_games, max_sims
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)

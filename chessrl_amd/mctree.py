@@ -25,22 +25,25 @@ from . import _lib
 
 class Node(object):
     """Read-only view of one root child.  ``state`` (the child's Game: root + our move + the
-    stored reply) is built on first access; the device tree keeps only boards."""
+    stored reply) is built on first access from the tree's SNAPSHOT of the root -- the copy taken
+    when the search ran, mctree.py:105-109 ``Node(root.get_copy())`` -- so it does not depend on
+    what the caller did to its own game afterwards; the device tree keeps only boards."""
 
-    def __init__(self, root_game, visits, value, prior, move, reply):
+    def __init__(self, root_snapshot, visits, value, prior, move, reply):
         self.visits, self.value, self.prior = int(visits), float(value), np.float32(prior)
         self.move, self.reply = move, reply
         self.vloss = 0
         self.children = []
-        self._root_game, self._state = root_game, None
+        self._root_snapshot, self._state = root_snapshot, None
 
     @property
     def state(self):
         if self._state is None:
-            g = self._root_game.get_copy()
-            g.move(self.move)
-            if self.reply is not None:
-                g.move(self.reply)
+            g = self._root_snapshot.get_copy()
+            for mv in (self.move, self.reply):
+                if mv is not None and not g.move(mv):
+                    raise RuntimeError("tree child %s%s does not replay on the root snapshot"
+                                       % (self.move, "+" + self.reply if self.reply else ""))
             self._state = g
         return self._state
 
@@ -56,7 +59,7 @@ class Tree(object):
         if not isinstance(root, Game):
             raise TypeError("root must be a chessrl_amd Game")
         self._game = root
-        self.root = _Root(root, 1, [])
+        self.root = _Root(root.get_copy(), 1, [])        # mctree.py:105-109: Node(root.get_copy())
 
 
 class SelfPlayTree(Tree):
@@ -66,7 +69,9 @@ class SelfPlayTree(Tree):
         self.num_threads = threads
 
     def search_move(self, agent, max_iters=200, verbose=False, noise=True, ai_move=False):
-        game = self._game
+        # the tree searches its own snapshot of the caller's game (taken at construction, as the
+        # reference's Node(root.get_copy())); one arena slot, returned when the tree is collected
+        game = self.root.state
         eng = agent.engine_for(max_iters)
         eng.ctx.copy_game_from(0, arena().ctx, game._slot)
         eng.search(max_iters)

@@ -99,17 +99,20 @@ def unpack(rows):
                        bool(rows[i, 4])) for i in range(len(rows))]
 
 
-def gather_blocks(block, device=None, stats=None):
+def gather_blocks(block, device=None, stats=None, force_collective=False):
     """Every rank's wire block on every rank: (rows of all ranks concatenated in rank order,
     per-rank row counts).  Two collectives -- the counts, then the blocks padded to the largest
     count -- and ONE device-to-host copy each; RCCL over xGMI with the ``nccl`` backend, ``gloo``
     in the CPU tests.  ``stats`` (a dict) receives the bytes moved and the wall time of the
-    exchange (host staging included)."""
+    exchange (host staging included).  A world of one returns the block as it is unless
+    ``force_collective`` (self-test of the RCCL path on a 1-GPU box: communicator, both
+    all_gathers and the device-to-host copies run on a single rank)."""
     import time
     import torch
     import torch.distributed as dist
     block = np.ascontiguousarray(block, dtype=np.int32)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    grouped = dist.is_available() and dist.is_initialized()
+    if not grouped or (dist.get_world_size() == 1 and not force_collective):
         if stats is not None:
             stats.update(world=1, rows=int(block.shape[0]), bytes_gathered=0, ms=0.0)
         return block, [block.shape[0]]

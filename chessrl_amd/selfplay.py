@@ -23,7 +23,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .engine import LockstepEngine, choose_children
+from .engine import LockstepEngine, choose_children, dirichlet_row
 from .records import GameRecord
 
 log = logging.getLogger("chessrl_amd.selfplay")
@@ -65,7 +65,7 @@ class SelfPlayRunner(object):
     """Lockstep self-play of ``n_parallel`` games on one GPU (one rank of ``world``)."""
 
     def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
-                 max_plies=4096, numpy_promotion="nep50", use_graph=True, total_games=None,
+                 max_plies=4096, numpy_promotion="auto", use_graph=True, total_games=None,
                  compact=True):
         self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
                                      numpy_promotion=numpy_promotion, use_graph=use_graph)
@@ -82,6 +82,8 @@ class SelfPlayRunner(object):
         self.moves_played = 0
         self.sims_run = 0
         self._sims_in_move = None
+        self._noise_rows = None                  # this move's Dirichlet draws, made while the GPU searches
+        self._root_legal = None                  # len(get_legal_moves()) of every root, read at the boundary
         self._start(np.ones(n_parallel, dtype=bool))
 
     # ---- slot management ------------------------------------------------------------------
@@ -112,8 +114,11 @@ class SelfPlayRunner(object):
     # ---- one move for every game --------------------------------------------------------------
     def begin_move(self):
         """Fresh tree per slot (agentdistributed.py:61-63) + the root's priors."""
+        if self.noise and self._root_legal is None:
+            self._root_legal = self.engine.ctx.legal_counts()
         self.engine.search_begin()
         self._sims_in_move = 0
+        self._noise_rows = None
 
     def step(self):
         """One lockstep simulation for every game; runs the move boundary when the budget of
@@ -122,10 +127,29 @@ class SelfPlayRunner(object):
             self.begin_move()
         self.engine.step()
         self._sims_in_move += 1
+        if self._sims_in_move == max(1, self.sims // 2):
+            self._draw_noise_ahead()
         if self._sims_in_move >= self.sims:
             self.end_move()
             return True
         return False
+
+    def _draw_noise_ahead(self):
+        """The Dirichlet draws of this move's ``compute_policy`` (mctree.py:317-320), made on the
+        host WHILE the GPU works through the steps already enqueued (launches are asynchronous; the
+        host is hundreds of steps ahead) instead of at the move boundary, where the GPU would wait
+        for them: 4096 per-game ``dirichlet`` calls are ~25 ms.  A draw needs the number of root
+        children the search will end with: every simulation expands one more child of the root until
+        all of its legal moves are expanded (mctree.py:216-231), so that is min(sims, legal moves of
+        the root), known since the last boundary.  Each game draws from its own stream, in the same
+        order and with the same arguments as at the boundary: the values are identical."""
+        if not self.noise or self._noise_rows is not None or self._root_legal is None:
+            return
+        n_final = np.minimum(self._root_legal[:self.G], self.sims)
+        rows = [None] * self.G
+        for g in np.nonzero((self.game_id >= 0) & (n_final > 0))[0]:
+            rows[g] = dirichlet_row(self.rngs[g], int(n_final[g]))
+        self._noise_rows = rows
 
     def end_move(self):
         """Last backprop, compute_policy + argmax on the host, the two pushes, harvest of
@@ -135,8 +159,10 @@ class SelfPlayRunner(object):
         rc = eng.ctx.root_children(("nchild", "visits", "root_visits"))
         _, plies, _ = eng.ctx.records(with_moves=False)
         nchild = np.where(self.game_id >= 0, rc["nchild"], 0)
+        rows = self._noise_rows if self._sims_in_move == self.sims else None    # (a shortened move draws here)
         chosen = choose_children(rc["visits"], nchild, rc["root_visits"], plies, noise=self.noise,
-                                 rngs=self.rngs)
+                                 rngs=self.rngs, noise_rows=rows)
+        self._noise_rows = None
         live = int((chosen >= 0).sum())
         eng.advance(chosen)
         self.moves_played += live
@@ -151,6 +177,8 @@ class SelfPlayRunner(object):
                                                 bool(self.color[g])))
             self._start(done)
             self._maybe_compact()
+        if self.noise:
+            self._root_legal = eng.ctx.legal_counts()       # the next roots (after pushes and refill)
         return live
 
     COMPACT_MIN = 64
@@ -194,6 +222,7 @@ class SelfPlayRunner(object):
         for _ in range(self.sims):
             self.engine.step()
         self._sims_in_move = self.sims
+        self._draw_noise_ahead()                 # the steps are enqueued; the GPU is busy with them
         return self.end_move() * self.sims
 
     def run(self, n_games=None, max_moves=None):
@@ -244,6 +273,10 @@ def main(argv=None):
     parser.add_argument("--no-noise", action="store_true")
     parser.add_argument("--rounds", type=int, default=1, help="play --games games, train, repeat")
     parser.add_argument("--no-train", action="store_true", help="only play and store the records")
+    parser.add_argument("--numpy-promotion", choices=["auto", "nep50", "legacy"], default="auto",
+                        help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87): 'legacy' = the float64 "
+                             "product of the reference's pinned numpy 1.17.2, 'nep50' = the float32 product "
+                             "of numpy >= 2, 'auto' = whichever the installed numpy computes")
     args = parser.parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO)
 
@@ -271,7 +304,7 @@ def main(argv=None):
     for rnd in range(args.rounds):
         runner = SelfPlayRunner(model, parallel, args.sims, seed=args.seed + rnd * args.games,
                                 noise=not args.no_noise, rank=rank, world=world, device=local,
-                                total_games=args.games)
+                                total_games=args.games, numpy_promotion=args.numpy_promotion)
         t0 = time.perf_counter()
         recs = runner.run()
         dt = time.perf_counter() - t0

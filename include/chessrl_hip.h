@@ -120,7 +120,8 @@ int  crl_copy_game(crl_ctx *ctx, int dst, int src);
  * encoder and the repetition rule read -- whatever position the source game started from.
  * The record must fit ctx's max_plies (CRL_ERR_CAPACITY otherwise).  Absolute slot numbers. */
 int  crl_copy_game_from(crl_ctx *ctx, int dst, crl_ctx *src_ctx, int src);
-/* Game.get_legal_moves (game.py:43-57): python-chess generation order. */
+/* Game.get_legal_moves (game.py:43-57): python-chess generation order.  moves may be NULL when
+ * only len(get_legal_moves()) is wanted (the 512-byte rows are then not copied back). */
 int  crl_legal_moves(crl_ctx *ctx, uint16_t *moves /*G x 256*/, int32_t *counts /*G*/);
 /* Game.move (game.py:28-41): applied iff in the legal list; ok[g] = 1/0; CRL_NO_MOVE skips. */
 int  crl_push_moves(crl_ctx *ctx, const uint16_t *moves /*G*/, uint8_t *ok /*G*/);
@@ -245,6 +246,12 @@ int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int
  * workgroup; they run the same kernels with half the boards per workgroup and twice the
  * workgroups (identical trunk bits).  enabled = 0 turns that off process-wide (default 1). */
 int  crl_trunk_set_small_batch(int enabled);
+
+/* Which kernel crl_trunk_forward (bitplanes = 0) / crl_trunk_forward_bitplanes (1) launches for this
+ * filter count and batch, written as rocprofv3 prints it without namespace and argument list
+ * ("k_trunk_x16<128, 4, 1, 0, 1, 0>"): measurement tools look their profiles up by it instead of
+ * restating the dispatch rule.  No reference counterpart (model.py:31-63 builds one Keras graph). */
+int  crl_trunk_kernel_name(int filters, int n_boards, int bitplanes, char *buf, int buf_len);
 
 /* ---- training step (model.py:83-99 fit_generator) --------------------
  * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'

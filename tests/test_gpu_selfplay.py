@@ -121,6 +121,18 @@ def test_dropin_objects_match_oracle():
     r = mcts_oracle.search(og, oagent, 40, noise=False)
     assert mv == r.moves
     assert [c.visits for c in tree.root.children] == r.visits and tree.root.visits == r.root_visits
+    # the tree holds its own snapshot of the root (mctree.py:105-109 Node(root.get_copy())): child
+    # states read AFTER the caller advanced its game are still root + our move + the reply
+    plies_before = len(g)
+    assert g.move(mv[0]) and g.move(mv[1]) and len(g) == plies_before + 2
+    assert tree.root.state is not g and len(tree.root.state) == plies_before
+    for ch in tree.root.children:
+        hist = ch.state.get_history()["moves"]
+        assert len(hist) == plies_before + (2 if ch.reply else 1)
+        assert hist[plies_before] == ch.move and (ch.reply is None or hist[-1] == ch.reply)
+    best = tree.root.children[int(np.argmax([c.visits for c in tree.root.children]))]
+    assert best.state.get_fen() == g.get_fen()
+    assert og.move(mv[0]) and og.move(mv[1])
     # agent.best_move(real_game=False) draws its noise from the global np.random stream
     np.random.seed(7)
     bm = agent.best_move(g, real_game=False, max_iters=40)

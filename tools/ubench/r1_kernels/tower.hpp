@@ -6,7 +6,7 @@
 #ifndef CRL_TUNING
 #error "tower.hpp belongs to the tuning build (-DCRL_TUNING) only"
 #endif
-#include "tower_common.hpp"
+#include "r1_common.hpp"
 
 namespace crl_tower {
 

@@ -53,14 +53,6 @@ struct Geo {
     __device__ static int wswz(int row) { return WCH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt()
-{
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-}
-
 template <class G>
 __device__ inline void stage_wtile_gen(const unsigned char *wts, lds_byte *lds, int t, int tid)
 {

@@ -31,55 +31,11 @@
 // per layer ~3 %.  Without staging the kernel runs at the rate of a bare MFMA micro-benchmark
 // with changing operands (1.5-1.6 PFLOP/s on this chip).
 #pragma once
-#include <type_traits>
-#include "tower_common.hpp"
+#include "r1_common.hpp"
 
 namespace crl_tower {
 
-constexpr int PIPE_RING = 4;                       // weight tiles in the LDS ring
 struct Frags { half8 x[2]; half8 w[2]; };          // operands of one 16-channel sub-step
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
-// ds_read_b128 the compiler does not see (see point 2 above)
-template <int OFF>
-__device__ __forceinline__ half8 lds_read16_asm(int addr)
-{
-    half8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-
-// Input given as 128 plane bitboards per board (u64 [n_boards][128]; bit sq of plane c = channel c
-// on square sq -- what the encoder builds before it would expand them, csrc/search.hpp): expand them
-// into the padded fp16 activation rows of the NB resident boards.  One item = (board, position,
-// 16 channels) = two 16-byte LDS stores; NB items per thread of a 512-thread workgroup.
-template <int NB, int AROW, int ABOARD>
-__device__ inline void expand_bitplanes(const unsigned char *planes, lds_byte *lds, size_t wg_board0, int tid)
-{
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(planes) + wg_board0 * 128;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        const int item = k * 512 + tid;
-        const int b = item >> 9, p = (item >> 3) & 63, c = item & 7;
-        const int sq = p ^ 56;                          // row 0 of the planes is rank 8
-        const unsigned long long *m = src + b * 128 + c * 16;
-        unsigned int w[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            w[q] = (((m[2 * q] >> sq) & 1) ? 0x3C00u : 0u) | (((m[2 * q + 1] >> sq) & 1) ? 0x3C000000u : 0u);
-        lds_byte *dst = lds + b * ABOARD + p * AROW + c * 32;
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
-        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst + 16) = u32x4{w[4], w[5], w[6], w[7]};
-    }
-}
 
 constexpr int P2_AROW = ROW_BYTES + 16;                             // padded activation row
 constexpr int P2_ABOARD = 64 * P2_AROW;

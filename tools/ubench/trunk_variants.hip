@@ -1,6 +1,6 @@
 // Scratch (GPU): time correct-result variants of the fused trunk kernels against production and
 // check that their outputs are bit-identical.  hipcc --offload-arch=gfx950 -O3 -std=c++17
-// -ffp-contract=off -I chessrl_amd/csrc tools/ubench/trunk_variants.hip -o tools/ubench/trunk_variants
+// -ffp-contract=off -I chessrl_amd/csrc -I tools/ubench/r1_kernels tools/ubench/trunk_variants.hip -o tools/ubench/trunk_variants
 //   ./trunk_variants [boards=4096] [reps=20]
 #define CRL_HARNESS 1
 #include "tower_pipe.hpp"
