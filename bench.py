@@ -74,6 +74,9 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="PyTorch-ROCm trunk instead of the HIP kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--precision", default="auto", choices=["auto", "f16", "f16x3"],
+                   help="fused-trunk arithmetic: f16 = one fp16 MFMA per product; f16x3 = hi/lo split operands, "
+                        "three MFMAs, fp32-grade; auto = f16 if it stays within 8e-4 of f16x3 on the probe positions")
     p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
                    help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
@@ -374,7 +377,7 @@ def main():
     from chessrl_amd.selfplay import SelfPlayRunner
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
     model = ChessModel(blocks=a.blocks, filters=a.filters, device="cuda:%d" % local, dtype=tdt,
-                       seed=a.seed, fused=not a.no_fused)
+                       seed=a.seed, fused=not a.no_fused, precision=a.precision)
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
                          device=local, use_graph=not a.no_graph, max_plies=max_plies,
@@ -437,7 +440,7 @@ def main():
             #  x G boards.
             k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50)
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            kern = trunk_kernel_name(F, G, int(eng.bitplanes))
+            kern = trunk_kernel_name(F, G, int(eng.bitplanes) | (2 if model.precision == "f16x3" else 0))
             k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (kern, B, G)
             traffic, traffic_src = pmc_traffic(kern, shape)
             # what one launch must move: the encoder's planes as handed over (1 KiB of plane
@@ -513,6 +516,7 @@ def main():
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
                        "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",
                        "tower_precision": getattr(model, "precision", a.dtype),
+                       "tower_precision_requested": a.precision, "tower_precision_probe": model.precision_probe,
                        "trunk_kernel": kern if model.fused else None,
                        "numpy_promotion": eng.numpy_promotion,
                        "parallelism": "games sharded, no collective on the hot path"},

@@ -39,6 +39,8 @@ PLANES = 128
 NO_MOVE = 0xFFFF
 RESULT_NONE = 2
 FLAG_NUMPY_LEGACY = 1
+TRUNK_BITPLANES = 1
+TRUNK_SPLIT = 2
 
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -49,7 +51,7 @@ SYMBOLS = [
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
-    "crl_trunk_forward_bitplanes", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
+    "crl_trunk_forward_bitplanes", "crl_trunk_forward_x", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
     "crl_heads_forward_legal",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
@@ -177,6 +179,7 @@ def lib():
     L.crl_trunk128_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]

@@ -572,7 +572,29 @@ static bool trunk_small_batch(int filters, int n_boards)
     return n_boards <= 128 * (filters == 256 ? 2 : 4) && g_small_batch.load() != 0;
 }
 
-static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, bool bits,
+struct TrunkPick { int nb, pair, group; };
+
+static TrunkPick trunk_pick(int filters, int n_boards, bool split)
+{
+    const bool small = trunk_small_batch(filters, n_boards);
+    if (split) {
+        // split precision ("f16x3"): activation rows hold hi and lo, so 128 / 256 filters keep half the
+        // boards per workgroup resident; 256 filters: plain ring of four (a fifth slot does not fit)
+        if (filters == 256) return { 1, 0, 0 };
+        if (filters == 128) return { 2, 1, 0 };
+        return { small ? 2 : 4, 0, 0 };
+    }
+    // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count; 128 and 256
+    // filters with one barrier per two weight tiles over a five-slot ring (PAIR)
+    // 64 filters at four boards per workgroup: taps in groups of three over a nine-slot ring (GROUP);
+    // at two boards per workgroup (batches <= 512) the plain ring of four measured faster
+    // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
+    // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
+    const int nb = filters == 256 ? (small ? 1 : 2) : (small ? 2 : 4);
+    return { nb, filters == 64 ? 0 : 1, (filters == 64 && nb == 4) ? 1 : 0 };
+}
+
+static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, int flags,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
                          const void *dev_head_b_f32, void *dev_head_out_f32)
@@ -582,39 +604,29 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     if (!dev_planes_f16 || !dev_wtiles_f16 || !dev_bias_f32 || (!dev_out_f32 && !dev_head_out_f32) ||
         (dev_head_out_f32 && (!dev_head_w_f32 || !dev_head_b_f32)) || n_boards < 4 ||
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
-        1 + 2 * n_blocks > crl_tower::MAX_CONVS)
+        1 + 2 * n_blocks > crl_tower::MAX_CONVS || (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
     kern_t kern = nullptr;
-    int lds_bytes = 0, boards_per_wg = 0;
-    // A batch that gives at most half of the 256 CUs a workgroup runs the half-size geometry
-    // (half the boards per workgroup, twice the workgroups): C2's 512 boards are 128 workgroups of 4.
-    const bool small = trunk_small_batch(filters, n_boards);
-    // production: the 16x16x32-MFMA kernels of tower_x16.hpp for every filter count; 128 and 256
-    // filters with one barrier per two weight tiles over a five-slot ring (PAIR)
-    // 64 filters at four boards per workgroup: taps in groups of three over a nine-slot ring (GROUP);
-    // at two boards per workgroup (batches <= 512) the plain ring of four measured faster
-#define CRL_X16(F_, NB_)                                                                        \
-    do {                                                                                         \
-        constexpr int pair = (F_ == 64) ? 0 : 1;                                                 \
-        constexpr int group = (F_ == 64 && NB_ == 4) ? 1 : 0;                                    \
-        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1, 0, pair, group>                         \
-                    : crl_tower::k_trunk_x16<F_, NB_, 0, 0, pair, group>;                        \
-        lds_bytes = crl_tower::Geo16<F_, NB_>::lds_bytes(group ? 9 : (pair ? 5 : crl_tower::PIPE_RING)); \
-        boards_per_wg = NB_;                                                                     \
-    } while (0)
-    if (filters == 256) {
-        if (small) CRL_X16(256, 1); else CRL_X16(256, 2);
-    } else if (filters == 64) {
-        if (small) CRL_X16(64, 2); else CRL_X16(64, 4);
-    } else {
-        if (small) CRL_X16(128, 2); else CRL_X16(128, 4);
+    int lds_bytes = 0;
+    const bool bits = flags & CRL_TRUNK_BITPLANES, split = flags & CRL_TRUNK_SPLIT;
+    const TrunkPick pk = trunk_pick(filters, n_boards, split);
+#define CRL_X16(F_, NB_, PAIR_, GROUP_, SPLIT_)                                                  \
+    if (filters == F_ && pk.nb == NB_ && pk.pair == PAIR_ && pk.group == GROUP_ && split == (SPLIT_ != 0)) { \
+        kern = bits ? crl_tower::k_trunk_x16<F_, NB_, 1, 0, PAIR_, GROUP_, SPLIT_>               \
+                    : crl_tower::k_trunk_x16<F_, NB_, 0, 0, PAIR_, GROUP_, SPLIT_>;              \
+        lds_bytes = crl_tower::Geo16<F_, NB_, SPLIT_>::lds_bytes(GROUP_ ? 9 : (PAIR_ ? 5 : crl_tower::PIPE_RING)); \
     }
+    CRL_X16(256, 1, 1, 0, 0) CRL_X16(256, 2, 1, 0, 0)
+    CRL_X16(64, 2, 0, 0, 0) CRL_X16(64, 4, 0, 1, 0)
+    CRL_X16(128, 2, 1, 0, 0) CRL_X16(128, 4, 1, 0, 0)
+    CRL_X16(256, 1, 0, 0, 1) CRL_X16(128, 2, 1, 0, 1) CRL_X16(64, 2, 0, 0, 1) CRL_X16(64, 4, 0, 0, 1)
 #undef CRL_X16
+    if (!kern) return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: no kernel for this shape");
     hipError_t ea = allow_big_lds((const void *)kern, lds_bytes);
     if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
-    hipLaunchKernelGGL(kern, dim3(n_boards / boards_per_wg), dim3(512),
+    hipLaunchKernelGGL(kern, dim3(n_boards / pk.nb), dim3(512),
                        lds_bytes, (hipStream_t)hip_stream,
                        (const unsigned char *)dev_planes_f16, (const unsigned char *)dev_wtiles_f16,
                        (const float *)dev_bias_f32, (float *)dev_out_f32, n_blocks,
@@ -625,15 +637,24 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     return CRL_OK;
 }
 
-int crl_trunk_kernel_name(int filters, int n_boards, int bitplanes, char *buf, int buf_len)
+int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int buf_len)
 {
-    if ((filters != 64 && filters != 128 && filters != 256) || n_boards < 4 || !buf || buf_len < 1)
+    if ((filters != 64 && filters != 128 && filters != 256) || n_boards < 4 || !buf || buf_len < 1 ||
+        (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_kernel_name: bad argument");
-    const bool small = trunk_small_batch(filters, n_boards);
-    const int nb = filters == 256 ? (small ? 1 : 2) : (small ? 2 : 4);
-    const int pair = filters == 64 ? 0 : 1, group = (filters == 64 && nb == 4) ? 1 : 0;
-    snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d>", filters, nb, bitplanes ? 1 : 0, pair, group);
+    const TrunkPick pk = trunk_pick(filters, n_boards, flags & CRL_TRUNK_SPLIT);
+    snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d, %d>", filters, pk.nb,
+             (flags & CRL_TRUNK_BITPLANES) ? 1 : 0, pk.pair, pk.group, (flags & CRL_TRUNK_SPLIT) ? 1 : 0);
     return CRL_OK;
+}
+
+int crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
+                        const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                        int n_boards, int n_blocks, const void *dev_head_w_f32,
+                        const void *dev_head_b_f32, void *dev_head_out_f32)
+{
+    return trunk_forward(hip_stream, filters, dev_planes, flags, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
 int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
@@ -641,7 +662,7 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
                       int n_boards, int n_blocks, const void *dev_head_w_f32,
                       const void *dev_head_b_f32, void *dev_head_out_f32)
 {
-    return trunk_forward(hip_stream, filters, dev_planes_f16, false, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+    return trunk_forward(hip_stream, filters, dev_planes_f16, 0, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
                          n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
@@ -650,7 +671,7 @@ int crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_b
                                 int n_boards, int n_blocks, const void *dev_head_w_f32,
                                 const void *dev_head_b_f32, void *dev_head_out_f32)
 {
-    return trunk_forward(hip_stream, filters, dev_bitplanes_u64, true, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+    return trunk_forward(hip_stream, filters, dev_bitplanes_u64, CRL_TRUNK_BITPLANES, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
                          n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 

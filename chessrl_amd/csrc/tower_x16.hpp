@@ -26,9 +26,19 @@
 
 namespace crl_tower {
 
-template <int F, int NB_>
+// SPLIT = 1 (precision mode "f16x3"): every activation is kept as TWO fp16 numbers, hi = fp16(x) and
+// lo = fp16(x - hi), side by side in its LDS row ([hi: F channels | lo: F channels]), the folded
+// weights likewise as two fp16 images, and a product is hi.Whi + hi.Wlo + lo.Whi (the dropped
+// lo.Wlo term is 2^-22 relative): three MFMAs for fp32-grade results -- the same device as
+// csrc/heads.hpp.  It is run as a convolution over an EXTENDED input: per spatial tap three "parts"
+// (x = hi against Whi, hi against Wlo, lo against Whi; the stem's 0/1 planes have no lo: two parts),
+// each a virtual tap like the channel halves of a 256-filter layer, so the tap loop, the weight
+// ring and the pipeline are the ones below; the weight image lists the planes in that order.
+template <int F, int NB_, int SPLIT_ = 0>
 struct Geo16 {
     static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
+    static constexpr int SPLIT = SPLIT_;
+    static constexpr int LO_OFF = F * 2;                // byte offset of the lo half inside an activation row
     static constexpr int NB = NB_;                      // boards per workgroup
     static constexpr int WPB = 8 / NB;                  // waves per board
     static constexpr int NT = (F == 64 && NB == 2) ? 1 : 2;
@@ -43,7 +53,8 @@ struct Geo16 {
     static constexpr int WCH = WROW / 16;
     static constexpr int TILE_BYTES = F * WROW;
     static constexpr int GL = TILE_BYTES / 8192;
-    static constexpr int AROW = (F < 128 ? 128 : F) * 2 + 32;
+    static constexpr int AROW_CH = (SPLIT ? 2 * F : F) < 128 ? 128 : (SPLIT ? 2 * F : F);   // channels a row holds
+    static constexpr int AROW = AROW_CH * 2 + 32;
     static constexpr int ABOARD = 64 * AROW;
     static constexpr int ZERO_OFF = NB * ABOARD;
     static constexpr int ZERO_BYTES = 16 * AROW;
@@ -177,7 +188,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 // workgroup) groups, so a tile is requested two (three) groups before it is read, and inside a
 // group the six sub-steps run back to back with their fragments fetched TWO sub-steps ahead into
 // three register buffers, across tap boundaries (not across layers: those activations do not exist yet).
-template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0, int GROUP = 0>
+template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0, int GROUP = 0, int SPLIT = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -189,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #if !defined(CRL_HARNESS)
     static_assert(ALT == 0, "diagnostic variants are for tools/ubench/trunk_variants.hip only");
 #endif
-    typedef Geo16<F, NB> G;
+    typedef Geo16<F, NB, SPLIT> G;
+    static_assert(!SPLIT || (!GROUP && (ALT == 0 || ALT == 2)), "split precision runs the plain / pair pipelines");
     constexpr int PT = G::PT, CT = G::CT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
     lds_byte *lds = (lds_byte *)lds_raw;
@@ -201,7 +213,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int r = lane & 15, q = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int n_convs = 1 + 2 * n_blocks;
-    const int tiles_stem = 9 * (128 / G::KT), tiles_conv = 9 * (F / G::KT);
+    // SPLIT: two parts per stem tap (Whi, Wlo against the exact 0/1 planes), three per block tap
+    const int tiles_stem = 9 * (SPLIT ? 2 : 1) * (128 / G::KT), tiles_conv = 9 * (SPLIT ? 3 : 1) * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
@@ -438,16 +451,27 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         // (GROUP: virtual taps of 64 channels, so it is the stem's 128 planes that split in two)
         const int hshift = GROUP ? (conv == 0 ? 1 : 0) : ((conv != 0 && F == 256) ? 1 : 0);
         constexpr int chstep = GROUP ? 128 : 256;       // bytes between the channel halves of a spatial tap
-        const int nv = 9 << hshift;
+        // SPLIT: a spatial tap is parts x pieces virtual taps (pieces = channel halves as above)
+        const int parts = SPLIT ? (conv == 0 ? 2 : 3) : 1;
+        const int per_tap = parts << hshift;
+        const int nv = 9 * per_tap;
         // Activation row address of block pt for virtual tap v: the lane's own row shifted by
         // (8 dy + dx) rows when that neighbour is on the board, else the zero row whose index has
         // the same residue mod 16 (same banks).  The zero-row address and the file test do not
         // depend on pt: per block only the rank test and one select remain.
         auto vtap_rows = [&](int v, int (&dst)[PT]) {
-            const int tap = v >> hshift;
+            int tap, choff;
+            if constexpr (SPLIT) {
+                // order inside a spatial tap: part (hi.Whi, hi.Wlo, lo.Whi) major, channel piece minor
+                tap = v / per_tap;
+                const int rem = v - tap * per_tap, part = rem >> hshift;
+                choff = (rem & ((1 << hshift) - 1)) * chstep + (part == 2 ? G::LO_OFF : 0);
+            } else {
+                tap = v >> hshift;
+                choff = (v & ((1 << hshift) - 1)) * chstep;
+            }
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
             const int shift = 8 * dy + dx;
-            const int choff = (v & ((1 << hshift) - 1)) * chstep;
             const int zrow = zero_q + ((r + shift) & 15) * G::AROW + choff;
             const int inb = base0 + shift * G::AROW + choff;
             // on-board tests as wave masks in SGPRs (computed once per kernel): per block only a
@@ -566,6 +590,45 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
         const half4 zero4 = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+        // SPLIT: the value goes back as hi = fp16(v) and lo = fp16(v - hi), lo LO_OFF bytes further
+        auto store_split = [&](int pt, int g, const f32x4v &a, const f32x4v &b) {
+            half8 hi8, lo8;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                hi8[j] = (_Float16)a[j];
+                hi8[4 + j] = (_Float16)b[j];
+                lo8[j] = (_Float16)(a[j] - (float)hi8[j]);
+                lo8[4 + j] = (_Float16)(b[j] - (float)hi8[4 + j]);
+            }
+            lds_byte *dst = lds + act_row0 + pt * 16 * G::AROW + (obase + 32 * g + 8 * q) * 2;
+            *reinterpret_cast<__attribute__((address_space(3))) half8 *>(dst) = hi8;
+            *reinterpret_cast<__attribute__((address_space(3))) half8 *>(dst + G::LO_OFF) = lo8;
+        };
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int g = 0; g < CT / 2; g++)
+#pragma unroll
+                for (int pt = 0; pt < PT; pt++) {
+                    f32x4v o[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int ct = 2 * g + h;
+                        if (kind == 0) {                // stem: linear, starts the skip stream
+                            o[h] = acc[pt][ct];
+                            res[pt][ct] = o[h];
+                        } else if (kind == 1) {         // conv1: ReLU
+#pragma unroll
+                            for (int j = 0; j < 4; j++) o[h][j] = fmaxf(acc[pt][ct][j], 0.f);
+                        } else {                        // conv2: + skip, ReLU, new skip
+                            const f32x4v sum = acc[pt][ct] + res[pt][ct];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) o[h][j] = fmaxf(sum[j], 0.f);
+                            res[pt][ct] = o[h];
+                        }
+                    }
+                    store_split(pt, g, o[0], o[1]);
+                }
+        } else
         if (kind == 1) {                                // conv1 of a block: ReLU, skip stream untouched
 #pragma unroll
             for (int g = 0; g < CT / 2; g++)

@@ -238,11 +238,14 @@ class LockstepEngine(object):
             self._step_body()
         self._bind_stream()
         self._graph = g
+        self._graph_epoch = getattr(self.evaluator, "graph_epoch", 0)
 
     def step(self):
         """One simulation for every game (enqueue only, no host sync)."""
         if self.use_graph:
-            if self._graph is None:
+            # an evaluator whose kernel choice changed (ChessModel precision "auto" after new weights)
+            # says so through graph_epoch: the captured launches are stale, capture again
+            if self._graph is None or self._graph_epoch != getattr(self.evaluator, "graph_epoch", 0):
                 self._capture()
             self._graph.replay()
         else:

@@ -88,6 +88,37 @@ def _read_weights(path):
     return dict(np.load(path))
 
 
+_PROBE = {}
+
+
+def _probe_bitplanes(device, n):
+    """``n`` positions as plane bitboards (int64 [n,128], the encoder's compact form) for the
+    precision probe of ``ChessModel(precision="auto")``: random playouts of 0..159 plies from the
+    start position, generated once per device by the rules and encoder kernels (fixed seed)."""
+    key = (str(device), n)
+    if key not in _PROBE:
+        from . import _lib
+        dev = torch.device(device)
+        ctx = _lib.Context(n, 1, max_plies=256, device=dev.index or 0)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.reset_games()
+        rng = np.random.RandomState(20260)
+        target = rng.randint(0, 160, size=n)
+        for ply in range(int(target.max())):
+            moves, counts = ctx.legal_moves()
+            pick = (rng.random_sample(n) * np.maximum(counts, 1)).astype(np.int64)
+            mv = moves[np.arange(n), pick]
+            mv = np.where((target > ply) & (counts > 0), mv, _lib.NO_MOVE).astype(np.uint16)
+            ctx.push_moves(mv)
+        ctx.set_plane_format(True)
+        planes = torch.zeros((n, PAD_PLANES), dtype=torch.int64, device=dev)
+        ctx.encode(planes.data_ptr())
+        ctx.sync()
+        ctx.close()
+        _PROBE[key] = planes
+    return _PROBE[key]
+
+
 class Tower(nn.Module):
     """Inference tower; input (B,128,8,8) channels_last fp16, i.e. NHWC memory."""
 
@@ -165,10 +196,30 @@ class ChessModel(object):
     (policy f32 [B,1968], value f32 [B]) CUDA tensors out.
     """
 
+    # precision modes of the fused HIP trunk (dtype float16):
+    #   "f16"    one fp16 MFMA per product, fp32 accumulation and skip stream.  Within 1e-3 of an fp32
+    #            evaluation for Keras-initialised and lightly trained towers; a sharp tower (peaked
+    #            policy, values near +-1, unit-gain layers) is off by up to ~2e-2
+    #            (profiles/r03/tower_sharp_probe*.json).
+    #   "f16x3"  every operand carried as hi + lo fp16 pairs, three MFMAs per product (CRL_TRUNK_SPLIT):
+    #            within ~1e-5..1e-4 of fp32 whatever the weights, at ~3.3x the trunk time.
+    #   "auto"   decided per weight set when it is loaded: both modes evaluate a fixed probe set of
+    #            positions (random playouts by the rules kernels) and "f16" is kept only if it stays
+    #            within PROBE_TOL of "f16x3" on all of them.
+    PRECISIONS = ("auto", "f16", "f16x3")
+    PROBE_TOL = 8e-4
+    PROBE_POSITIONS = 256
+
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
-                 dtype=torch.float16, seed=0, fused=True):
+                 dtype=torch.float16, seed=0, fused=True, precision="auto"):
         self.compiled = bool(compile_model)      # model.py:69-72: Adam(lr=0.002), cce + mse
         self._trainer = None
+        if precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % (self.PRECISIONS,))
+        self.precision_requested = precision
+        self.precision = None                    # resolved per weight set ("f16" / "f16x3"; the dtype otherwise)
+        self.precision_probe = None              # what "auto" measured
+        self.graph_epoch = 0                     # bumped when the kernel a captured graph holds changes
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
@@ -201,6 +252,9 @@ class ChessModel(object):
                           and 1 + 2 * blocks <= 41)
         if self.fused:
             self._pack_fused(weights)
+            self._resolve_precision()
+        else:
+            self.precision = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[self.dtype]
 
     @staticmethod
     def _plane_order(F_):
@@ -224,27 +278,44 @@ class ChessModel(object):
         names = [("stem", None)]
         for i in range(self.blocks):
             names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
-        tiles, biases = [], []
+        want_f16 = self.precision_requested in ("auto", "f16")
+        want_x3 = self.precision_requested in ("auto", "f16x3")
+        tiles, tiles3, biases = [], [], []
+
+        def planes_of(k16):
+            """fp16 OIHW kernel -> [tap][in-ch/32][row][chunk][8] in the LDS image's order."""
+            cin = k16.shape[1]                                 # 128 for the stem, F otherwise
+            t = k16.permute(2, 3, 0, 1).reshape(9, F_, cin // 32, 4, 8)                  # [tap][o][g][chunk][8]
+            t = t[:, chan_t]                                                              # rows in plane order
+            t = t.permute(0, 2, 1, 3, 4)                                                  # [tap][g][row][chunk][8]
+            idx = src_chunk.view(1, 1, F_, 4, 1).expand(9, cin // 32, F_, 4, 8)
+            return torch.gather(t, 3, idx)                                                # chunk ^ swizzle(row)
+
         for conv, bn in names:
             k, b = _fold(w, conv, bn)                          # OIHW fp32
             if conv == "stem" and k.shape[1] < PAD_PLANES:    # 127 planes -> 128 channels
                 kp = torch.zeros(k.shape[0], PAD_PLANES, 3, 3)
                 kp[:, :k.shape[1]] = k
                 k = kp
-            cin = k.shape[1]                                   # 128 for the stem, F otherwise
-            t = k.permute(2, 3, 0, 1).reshape(9, F_, cin // 32, 4, 8)                    # [tap][o][g][chunk][8]
-            t = t[:, chan_t]                                                              # rows in plane order
-            t = t.permute(0, 2, 1, 3, 4)                                                  # [tap][g][row][chunk][8]
-            idx = src_chunk.view(1, 1, F_, 4, 1).expand(9, cin // 32, F_, 4, 8)
-            t = torch.gather(t, 3, idx)                                                   # chunk ^ swizzle(row)
-            tiles.append(t.contiguous().reshape(-1))
+            hi = k.to(torch.float16)
+            t_hi = planes_of(hi)
+            if want_f16:
+                tiles.append(t_hi.contiguous().reshape(-1))
+            if want_x3:
+                # CRL_TRUNK_SPLIT: per tap the planes of Whi, of Wlo = fp16(W - Whi), and of Whi again
+                # (products hi.Whi, hi.Wlo, lo.Whi); the stem's 0/1 planes have no lo part: Whi, Wlo
+                t_lo = planes_of((k - hi.float()).to(torch.float16))
+                parts = [t_hi, t_lo] if conv == "stem" else [t_hi, t_lo, t_hi]
+                tiles3.append(torch.stack(parts, dim=1).contiguous().reshape(-1))          # [tap][part][g][row]...
             biases.append(b)
         kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][F][1][1]
         kv, bv = _fold(w, "value.conv", "value.bn")            # [1][F][1][1]
-        new = (torch.cat(tiles).to(torch.float16), torch.stack(biases).float(),
+        empty = torch.zeros(8, dtype=torch.float16)
+        new = (torch.cat(tiles) if want_f16 else empty, torch.cat(tiles3) if want_x3 else empty,
+               torch.stack(biases).float(),
                torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).float(), torch.cat([bp, bv]).float())
         new = new + self._pack_dense(w)
-        names = ("_wtiles", "_wbias", "_head_w", "_head_b", "_pol_wp", "_pol_bias", "_val_w1p", "_val_b1", "_val_w2")
+        names = ("_wtiles", "_wtiles3", "_wbias", "_head_w", "_head_b", "_pol_wp", "_pol_bias", "_val_w1p", "_val_b1", "_val_w2")
         if getattr(self, "_wtiles", None) is None:
             for name, t in zip(names, new):
                 setattr(self, name, t.to(self.device).contiguous())
@@ -277,7 +348,7 @@ class ChessModel(object):
                 torch.cat([torch.from_numpy(np.asarray(w["value.dense2.kernel"], np.float32)).reshape(-1),
                            torch.from_numpy(np.asarray(w["value.dense2.bias"], np.float32)).reshape(-1)]))    # w2, b2
 
-    def _run_fused(self, planes, want_trunk=False):
+    def _run_fused(self, planes, want_trunk=False, precision=None):
         """One launch of the fused trunk kernel.  ``planes``: fp16 NHWC [B,8,8,128], or int64
         [B,128] plane bitboards (the encoder's compact form; the kernel expands them on chip).
         Returns (trunk fp32 [B,8,8,F] or None, head activations fp32 [B,192] = ReLU(1x1 head
@@ -301,24 +372,44 @@ class ChessModel(object):
         trunk = (torch.empty((bp, 8, 8, self.filters), dtype=torch.float32, device=self.device)
                  if want_trunk else None)
         heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
-        fn = _lib.lib().crl_trunk_forward_bitplanes if bits else _lib.lib().crl_trunk_forward
-        rc = fn(
-            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters,
-            ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(self._wtiles.data_ptr()),
+        split = (precision or self.precision) == "f16x3"
+        flags = (_lib.TRUNK_BITPLANES if bits else 0) | (_lib.TRUNK_SPLIT if split else 0)
+        rc = _lib.lib().crl_trunk_forward_x(
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters, flags,
+            ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p((self._wtiles3 if split else self._wtiles).data_ptr()),
             ctypes.c_void_p(self._wbias.data_ptr()),
             ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
             ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
             ctypes.c_void_p(heads.data_ptr()))
         if rc != 0:
-            raise _lib.HipLibraryError("crl_trunk_forward failed (%d)" % rc)
+            raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
         return (trunk[:b] if want_trunk else None), heads[:b]
 
-    def _forward_fused(self, planes, pol_out=None, val_out=None):
+    def _resolve_precision(self):
+        """Fix ``self.precision`` for the weights just packed.  "auto": evaluate the probe positions in
+        both modes and keep the single-MFMA mode only if its outputs stay within PROBE_TOL of the
+        split mode's (which is itself within ~1e-4 of fp32).  A changed decision invalidates captured
+        hipGraphs (``graph_epoch``; LockstepEngine re-captures)."""
+        before = self.precision
+        if self.precision_requested != "auto":
+            self.precision = self.precision_requested
+        else:
+            planes = _probe_bitplanes(self.device, self.PROBE_POSITIONS)
+            pa, va = self._forward_fused(planes, precision="f16")
+            pb, vb = self._forward_fused(planes, precision="f16x3")
+            dp, dv = float((pa - pb).abs().max()), float((va - vb).abs().max())
+            self.precision = "f16" if max(dp, dv) <= self.PROBE_TOL else "f16x3"
+            self.precision_probe = {"positions": int(planes.shape[0]), "dpolicy_max": dp, "dvalue_max": dv,
+                                    "tolerance": self.PROBE_TOL, "chosen": self.precision}
+        if before is not None and before != self.precision:
+            self.graph_epoch += 1
+
+    def _forward_fused(self, planes, pol_out=None, val_out=None, precision=None):
         """Fused trunk + head convs in one HIP kernel, then the dense layers (model.py:44-48,56-61)
         in one launch per head (csrc/heads.hpp), written straight into the caller's buffers."""
         import ctypes
         from . import _lib
-        _, hp = self._run_fused(planes)
+        _, hp = self._run_fused(planes, precision=precision)
         b = hp.shape[0]
         want_value = not (pol_out is not None and val_out is None)   # S1 evaluations only choose the reply
         p = pol_out if pol_out is not None else torch.empty((b, N_POLICY), dtype=torch.float32, device=self.device)

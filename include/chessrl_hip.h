@@ -209,6 +209,21 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
                        int n_boards, int n_blocks, const void *dev_head_w_f32,
                        const void *dev_head_b_f32, void *dev_head_out_f32);
 
+/* The general form.  flags: CRL_TRUNK_BITPLANES = dev_planes holds plane bitboards (as
+ * crl_trunk_forward_bitplanes); CRL_TRUNK_SPLIT = precision mode "f16x3": every operand is carried
+ * as two fp16 numbers (hi + lo) and every product is three MFMAs (hi.Whi + hi.Wlo + lo.Whi, fp32
+ * accumulation), which puts the outputs within ~1e-5 of an fp32 evaluation of the same weights
+ * whatever the weights are (one fp16 MFMA per product is within 1e-3 of fp32 for Keras-initialised
+ * and lightly trained towers but not for sharp ones; model.py:31-63 runs fp32).  The weight image
+ * then lists, per conv and spatial tap, the planes of Whi, of Wlo = fp16(W - Whi), and of Whi
+ * again (the stem, whose 0/1 input has no lo part: Whi, Wlo), each in the plane order above. */
+#define CRL_TRUNK_BITPLANES 1
+#define CRL_TRUNK_SPLIT 2
+int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
+                         const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
+                         int n_boards, int n_blocks, const void *dev_head_w_f32,
+                         const void *dev_head_b_f32, void *dev_head_out_f32);
+
 /* crl_trunk_forward with the input given as plane bitboards (CRL_PLANES_BITS), uint64
  * [n_boards][128]; everything else as above. */
 int  crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_bitplanes_u64,
@@ -247,11 +262,11 @@ int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int
  * workgroups (identical trunk bits).  enabled = 0 turns that off process-wide (default 1). */
 int  crl_trunk_set_small_batch(int enabled);
 
-/* Which kernel crl_trunk_forward (bitplanes = 0) / crl_trunk_forward_bitplanes (1) launches for this
- * filter count and batch, written as rocprofv3 prints it without namespace and argument list
- * ("k_trunk_x16<128, 4, 1, 0, 1, 0>"): measurement tools look their profiles up by it instead of
- * restating the dispatch rule.  No reference counterpart (model.py:31-63 builds one Keras graph). */
-int  crl_trunk_kernel_name(int filters, int n_boards, int bitplanes, char *buf, int buf_len);
+/* Which kernel crl_trunk_forward_x launches for this filter count, batch and flags, written as
+ * rocprofv3 prints it without namespace and argument list ("k_trunk_x16<128, 4, 1, 0, 1, 0, 0>"):
+ * measurement tools look their profiles up by it instead of restating the dispatch rule.  No
+ * reference counterpart (model.py:31-63 builds one Keras graph). */
+int  crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int buf_len);
 
 /* ---- training step (model.py:83-99 fit_generator) --------------------
  * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'

@@ -82,6 +82,64 @@ def init_weights(blocks, filters, seed=0, randomize_bn=False):
     return w
 
 
+@torch.no_grad()
+def calibrated_weights(blocks, filters, planes, seed=0, policy_logit_std=3.0, value_preact_std=1.0):
+    """Weights that make the tower's outputs SENSITIVE to its input, the way a trained tower's are
+    (a random-init or barely trained tower is nearly constant: uniform policy, value ~ 0, so a small
+    absolute output error proves nothing).  Data-dependent initialisation over ``planes`` (B,8,8,127),
+    a sample of real positions: random kernels and biases, and per BatchNorm layer
+
+      * moving mean / variance := the statistics of that layer's input over the sample, so every
+        normalised activation has zero mean and unit variance -- each layer has unit gain, errors
+        neither die out (contractive net) nor blow up (random statistics);
+      * gamma in [0.6, 1.4], beta in [-0.4, 0.4] at random: channels differ, ReLUs cut at different
+        points;
+
+    then the policy Dense kernel is scaled so that the logits have standard deviation
+    ``policy_logit_std`` over the sample (peaked softmax: best moves of 0.3 and more) and the last
+    value Dense so that the tanh pre-activation has standard deviation ``value_preact_std`` (values
+    spread over (-1, 1))."""
+    rng = np.random.default_rng(seed)
+    w = init_weights(blocks, filters, seed=seed)
+    x = torch.as_tensor(planes)[..., :IN_PLANES].to(torch.float32).permute(0, 3, 1, 2)
+
+    def rand_bias(name):
+        n = w[name + ".bias"].shape[0]
+        w[name + ".bias"] = rng.normal(0, 0.05, n).astype(np.float32)
+
+    def calibrate(name, z):
+        c = z.shape[1]
+        w[name + ".mean"] = z.mean(dim=(0, 2, 3)).numpy().astype(np.float32)
+        w[name + ".var"] = np.maximum(z.var(dim=(0, 2, 3), unbiased=False).numpy(), 1e-4).astype(np.float32)
+        w[name + ".gamma"] = rng.uniform(0.6, 1.4, c).astype(np.float32)
+        w[name + ".beta"] = rng.uniform(-0.4, 0.4, c).astype(np.float32)
+        return _bn(z, w, name)
+
+    rand_bias("stem")
+    x = _conv(x, w, "stem", 1)
+    for i in range(blocks):
+        rand_bias("block%d.conv1" % i)
+        rand_bias("block%d.conv2" % i)
+        y = F.relu(calibrate("block%d.bn1" % i, _conv(x, w, "block%d.conv1" % i, 1)))
+        y = calibrate("block%d.bn2" % i, _conv(y, w, "block%d.conv2" % i, 1))
+        x = F.relu(x + y)
+    rand_bias("policy.conv")
+    p = F.relu(calibrate("policy.bn", _conv(x, w, "policy.conv", 0)))
+    p = p.permute(0, 2, 3, 1).reshape(p.shape[0], -1)
+    w["policy.dense.bias"] = rng.normal(0, 1.0, N_POLICY).astype(np.float32)
+    logits = p @ torch.from_numpy(w["policy.dense.kernel"])
+    w["policy.dense.kernel"] = (w["policy.dense.kernel"] * (policy_logit_std / float(logits.std()))).astype(np.float32)
+    rand_bias("value.conv")
+    v = F.relu(calibrate("value.bn", _conv(x, w, "value.conv", 0)))
+    v = v.permute(0, 2, 3, 1).reshape(v.shape[0], -1)
+    w["value.dense1.bias"] = rng.normal(0, 0.1, 256).astype(np.float32)
+    v = F.relu(v @ torch.from_numpy(w["value.dense1.kernel"]) + torch.from_numpy(w["value.dense1.bias"]))
+    pre = v @ torch.from_numpy(w["value.dense2.kernel"])
+    w["value.dense2.kernel"] = (w["value.dense2.kernel"] * (value_preact_std / float(pre.std()))).astype(np.float32)
+    w["value.dense2.bias"] = np.array([-float(pre.mean()) * value_preact_std / float(pre.std())], np.float32)
+    return w
+
+
 def _conv(x, w, name, pad):
     k = torch.from_numpy(w[name + ".kernel"]).permute(3, 2, 0, 1)       # HWIO -> OIHW
     return F.conv2d(x, k, torch.from_numpy(w[name + ".bias"]), padding=pad)

@@ -402,3 +402,41 @@ def test_cli_two_ranks_play_train_and_share_the_weights(tmp_path):
     single = json.load(open(os.path.join(one, "gameplays.json")))
     assert [g["moves"] for g in recs[:6]] == [g["moves"] for g in single]
     assert len([l for l in open(os.path.join(d, "train_log.jsonl"))]) == 2
+
+
+def test_rolling_rounds_play_the_same_games_and_hand_rounds_over_in_order():
+    """Rolling rounds (SelfPlayRunner.run_rolling): the batch refills from the next round's ids while
+    a round's long games finish.  What a game plays depends on its id only, so the three rounds of
+    100 games must be, game for game, the games a one-shot run of 300 plays; rounds are handed
+    over complete, in order, each as soon as its last game has ended (earlier than the end of the
+    run for all but the last), and a weight update between rounds -- in place, under the captured
+    hipGraph -- takes effect for the games still running."""
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=17, prior_shift=30)
+    kw = dict(n_parallel=128, sims=2, seed=9, noise=True, total_games=300, max_plies=2048)
+    b = SelfPlayRunner(net.to("cuda:0"), **kw)
+    rb = {r.game_id: r for r in b.run()}
+    b.close()
+    a = SelfPlayRunner(net.to("cuda:0"), round_size=100, **kw)
+    handed, moves_at = [], []
+
+    def on_round(r, recs):
+        handed.append((r, sorted(x.game_id for x in recs)))
+        moves_at.append(a.moves_played)
+        for x in recs:
+            assert x == rb[x.game_id], x.game_id
+
+    assert a.run_rolling(3, on_round=on_round) == 3
+    assert [r for r, _ in handed] == [0, 1, 2]
+    assert [ids for _, ids in handed] == [list(range(100)), list(range(100, 200)), list(range(200, 300))]
+    assert moves_at[0] < moves_at[1] < moves_at[2] and not a.finished and not a.active().any()
+    a.close()
+    # one round per 64 ids on a 2-rank shard: shares are 32 ids each and complete independently
+    c = SelfPlayRunner(net.to("cuda:0"), n_parallel=32, sims=2, seed=9, noise=True, total_games=128,
+                       max_plies=2048, round_size=64, rank=1, world=2)
+    assert c._round_share(0) == 32 and c._round_share(1) == 32 and c._round_share(2) == 0
+    while c.rounds_complete() < 2:
+        c.play_move()
+    assert sorted(x.game_id for x in c.take_round(0)) == list(range(1, 64, 2))
+    assert all(x == rb[x.game_id] for x in c.take_round(1))
+    c.close()

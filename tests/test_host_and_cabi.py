@@ -257,6 +257,7 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
     w = tower_oracle.init_weights(blocks, F_, seed=3, randomize_bn=True)
     m = M.ChessModel.__new__(M.ChessModel)
     m.filters, m.blocks, m.device = F_, blocks, torch.device("cpu")
+    m.precision_requested = "auto"                                   # packs both images
     m._pack_fused(w)
     img = m._wtiles.float().numpy()
     assert m._wtiles.dtype == torch.float16
@@ -278,3 +279,24 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
             assert planes[tap, g, r, pos, e] == want, (conv, tap, g, r, c, e)
         off += 9 * cin * F_
     assert sorted({(r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3) for r in range(F_)}) == list(range(F_))
+    # the split-precision image (CRL_TRUNK_SPLIT): per tap the planes of Whi, Wlo = fp16(W - Whi) and
+    # Whi again (stem: Whi, Wlo), each in the same plane order; hi + lo carries W to ~2^-22
+    img3 = m._wtiles3.float().numpy()
+    assert img3.size == 2 * 9 * 128 * F_ + 2 * 3 * 9 * F_ * F_
+    off = 0
+    for conv, bn in convs:
+        k, _ = M._fold(w, conv, bn)
+        k = k.numpy()
+        hi = k.astype(np.float16).astype(np.float32)
+        lo = (k - hi).astype(np.float16).astype(np.float32)
+        cin = 128 if conv == "stem" else F_
+        parts = [hi, lo] if conv == "stem" else [hi, lo, hi]
+        planes = img3[off:off + len(parts) * 9 * cin * F_].reshape(9, len(parts), cin // 32, F_, 4, 8)
+        for _ in range(400):
+            tap, part, g, r, c, e = (int(rng.integers(n)) for n in (9, len(parts), cin // 32, F_, 4, 8))
+            chan = (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3)
+            i = 32 * g + 8 * c + e
+            want = parts[part][chan, i, tap // 3, tap % 3] if i < k.shape[1] else 0.0
+            assert planes[tap, part, g, r, c ^ ((-(r >> 2)) & 3), e] == want, (conv, tap, part, g, r, c, e)
+        assert np.abs(hi + lo - k).max() <= 2.0 ** -20 * np.abs(k).max()
+        off += len(parts) * 9 * cin * F_

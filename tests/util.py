@@ -58,3 +58,55 @@ def oracle_games_parallel(net_kw, seed, sims, gid_colors, workers=None):
             raise RuntimeError("oracle worker failed")
         out.update({int(k): v for k, v in json.loads(data).items()})
     return out
+
+
+def selfplay_position_prefixes(n, seed=5, games=96, sims=12):
+    """``n`` positions harvested from REAL self-play, as move-id prefixes: complete games played by
+    the lockstep runner (6x64 random-init tower, Dirichlet noise), then (game, ply) pairs drawn
+    evenly over each game's length -- openings, middle games, the long endgames random-init play
+    drifts into, positions after promotions, captures and castling.  Returns (prefixes, info)."""
+    import numpy as np
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    run = SelfPlayRunner(ChessModel(blocks=6, filters=64, seed=seed), games, sims, seed=seed, noise=True,
+                         total_games=games, max_plies=1024)
+    recs = run.run()
+    run.close()
+    rng = np.random.default_rng(seed)
+    moves = [np.asarray(r.moves, dtype=np.uint16) for r in recs if len(r.moves) >= 8]
+    total = sum(len(m) for m in moves)
+    prefixes = []
+    for m in moves:                                         # evenly spaced plies of every game
+        k = max(1, int(round(n * len(m) / total)))
+        for ply in np.unique(rng.integers(0, len(m) + 1, size=k)):
+            prefixes.append(m[:int(ply)])
+    while len(prefixes) < n:                                # top up (rounding, duplicates)
+        m = moves[int(rng.integers(len(moves)))]
+        prefixes.append(m[:int(rng.integers(0, len(m) + 1))])
+    prefixes = prefixes[:n]
+    plies = np.array([len(p) for p in prefixes])
+    info = {"games": len(moves), "plies_min": int(plies.min()), "plies_max": int(plies.max()),
+            "plies_mean": float(plies.mean()),
+            "after_a_promotion": int(sum(bool(((p >> 12) & 7).any()) for p in prefixes)),
+            "opening_lt_20": int((plies < 20).sum()), "late_ge_150": int((plies >= 150).sum())}
+    return prefixes, info
+
+
+def encode_prefixes(model, prefixes):
+    """(model input as the search hands it over -- plane bitboards for the fused trunk --, the same
+    positions as fp32 NHWC planes [n,8,8,127] for the fp32 oracle), both from the HIP encoder."""
+    import numpy as np
+    from chessrl_amd.engine import LockstepEngine
+    n = len(prefixes)
+    a = LockstepEngine(model, n_games=n, max_sims=2, use_graph=False, max_plies=1024)
+    a.load_moves(prefixes)
+    a.ctx.encode(a.planes_s1.data_ptr())
+    x = a.planes_s1.clone()
+    a.close()
+    b = LockstepEngine(model, n_games=n, max_sims=2, use_graph=False, max_plies=1024, bitplanes=False,
+                       legal_priors=False)
+    b.load_moves(prefixes)
+    b.ctx.encode(b.planes_s1.data_ptr())
+    planes = b.planes_s1[..., :127].float().cpu().numpy()
+    b.close()
+    return x, planes
