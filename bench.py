@@ -74,9 +74,14 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="PyTorch-ROCm trunk instead of the HIP kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--precision", default="auto", choices=["auto", "f16", "f16x3"],
-                   help="fused-trunk arithmetic: f16 = one fp16 MFMA per product; f16x3 = hi/lo split operands, "
-                        "three MFMAs, fp32-grade; auto = f16 if it stays within 8e-4 of f16x3 on the probe positions")
+    p.add_argument("--precision", default="f16", choices=["auto", "f16", "f16x3"],
+                   help="fused-trunk arithmetic of the timed region.  f16 (default) = one fp16 MFMA per product, "
+                        "BASELINE's 'fp16 MFMA inference'; f16x3 = hi/lo split operands, three MFMAs, fp32-grade "
+                        "(within 1e-4 of fp32 on any weights); auto = what the product picks for these weights. "
+                        "With f16 the line also carries the strict mode's rate (precision_modes) and how far "
+                        "f16 is from it on the probe positions")
+    p.add_argument("--strict-steps", type=int, default=40,
+                   help="steps of the f16x3 leg timed after the main window (0 = skip)")
     p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
                    help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
@@ -502,6 +507,35 @@ def main():
                                 "the window already holds %d boundaries: value_incl_boundaries = value" % inside)
         else:
             incl = None
+        # ---- the other precision mode on the same games and weights (short window, mid-move) --------
+        modes = None
+        if model.fused:
+            modes = {model.precision: {"simulations_per_s": total_sims / max_dt, "ms_per_step": max_dt / a.steps * 1e3,
+                                       "trunk_kernel": kern, "trunk_launch_ms": k_ms}}
+            modes["f16_vs_f16x3_on_probe"] = model.probe_error()
+            if model.precision == "f16" and a.strict_steps > 0 and world == 1:
+                model.set_precision("f16x3")
+                run.begin_move()                                # fresh trees (the profiled move is abandoned)
+                pre = min(max(8, run.sims // 4), run.sims // 2)
+                n3 = max(1, min(a.strict_steps, run.sims - pre - 1))
+                for _ in range(pre):
+                    eng.step()                                  # (re-captures the graph) to mid-move
+                torch.cuda.synchronize()
+                cs0 = eng.ctx.counters()["sims"]
+                ts = time.perf_counter()
+                for _ in range(n3):
+                    eng.step()
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - ts
+                run._sims_in_move = pre + n3
+                k3 = trunk_kernel_name(F, G, int(eng.bitplanes) | 2)
+                modes["f16x3"] = {"simulations_per_s": (eng.ctx.counters()["sims"] - cs0) / dts,
+                                  "ms_per_step": dts / n3 * 1e3, "steps": n3,
+                                  "trunk_kernel": k3,
+                                  "trunk_launch_ms": event_time_ms(lambda: model._run_fused(eng.planes_s2), 10),
+                                  "note": "same games, same weights, three MFMAs per product: the mode "
+                                          "precision='auto' picks when f16 is not within 1e-3"}
+                model.set_precision("f16")
         cfg_name = {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
                     (4096, 800, 20, 256): "C5 per-GPU shard"}.get((G, a.sims, B, F), "custom")
         out = {
@@ -532,7 +566,7 @@ def main():
                                              if (a.sims, B, F) == (800, 10, 128) else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
-            "roofline": roof, "roofline_tree": tree,
+            "roofline": roof, "roofline_tree": tree, "precision_modes": modes,
         }
         if gather is not None:
             out["record_gather"] = gather

@@ -90,9 +90,11 @@ struct Geo16 {
 };
 
 // stage weight tile t (global image = the plane image above, contiguous) into ring slot t & 3.
-// (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5, 6: timing-only builds without the weight staging, without
-// the per-tile barrier, without both, without the fragment reads from LDS -- harness diagnostics, WRONG
-// results, never dispatched.)
+// (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5, 6, 7: timing-only builds without the weight staging, without
+// the per-tile barrier, without both, without the fragment reads from LDS, with NOTHING BUT the weight
+// staging, barriers and epilogues (no fragment reads, no MFMAs) -- harness diagnostics, WRONG
+// results, never dispatched.  ALT 8: correct results, the weight-fragment reads of the next sub-step
+// issued one by one between the MFMAs of half 1 instead of in one clump before them.)
 // ALT = 0: every wave moves GL pieces of 1 KiB.  ALT = 1: the tile is moved by ONE half of the
 // workgroup -- waves 0-3 move even tiles, waves 4-7 odd tiles, 2 GL pieces each -- so that of the
 // two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
-    static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2)), "pair publishing: even tile counts per layer");
+    static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2 || ALT == 7 || ALT == 8)), "pair publishing: even tile counts per layer");
     constexpr int GK = 3;                               // GROUP: taps (= tiles) per barrier
     constexpr int GRG = NB == 2 ? 4 : 3;                // GROUP: groups in the weight ring
     constexpr int GR = GK * GRG;                        // GROUP: ring slots
@@ -324,12 +326,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             const int t_tap0 = t;
             auto fetch_xa = [&](auto IC, bool next_tap) {
                 constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }       // timing only: no fragment reads
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xa[pt] = lds_read16_asm<i * 64>(ab[next_tap ? 1 : 0][pt]);
             };
             auto fetch_xb = [&](auto IC) {
                 constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
@@ -348,14 +352,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 wv[0] = w0 + (t_tap0 & (PIPE_RING - 1)) * G::TILE_BYTES;
                 wv_nxt = w0 + ((t_tap0 + TPT) & (PIPE_RING - 1)) * G::TILE_BYTES;
             }
+            auto fetch_w1 = [&](auto IC, auto CC, bool next_tap, half8 (&dst)[CT]) {
+                constexpr int i = decltype(IC)::value, ct = decltype(CC)::value;
+                constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (PAIR ? 0 : (i / G::SPT) * G::TILE_BYTES);
+                dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv[PAIR ? i / G::SPT : 0]);
+            };
             auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
-                constexpr int i = decltype(IC)::value;
+                if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }
-                static_for<0, CT>([&](auto CC) {
-                    constexpr int ct = decltype(CC)::value;
-                    constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (PAIR ? 0 : (i / G::SPT) * G::TILE_BYTES);
-                    dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv[PAIR ? i / G::SPT : 0]);
-                });
+                static_for<0, CT>([&](auto CC) { fetch_w1(IC, CC, next_tap, dst); });
             };
             if (first_tap) {
                 fetch_xa(std::integral_constant<int, 0>{}, false);
@@ -413,15 +418,42 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 fetch_xb(IC);
                 wait_lgkm<HP>();                         // xa and w[cur] have landed
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ALT != 7) {
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++)
 #pragma unroll
                     for (int ct = 0; ct < CT; ct++)
                         acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xa[pt], acc[pt][ct], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- half 1: position blocks [HP, PT); prefetch the next sub-step
                 constexpr bool wrap = i + 1 >= NS;
                 bool issued = false;
+                if constexpr (ALT == 8) {
+                    // the next sub-step's activation fragments before the wait as ever; its CT weight
+                    // fragments one by one behind the first CT MFMAs of this half
+                    if (!wrap || !last_tap) {
+                        issued = true;
+                        if constexpr (wrap) fetch_xa(std::integral_constant<int, 0>{}, true);
+                        else fetch_xa(std::integral_constant<int, i + 1>{}, false);
+                    }
+                    if (!issued) wait_lgkm<0>();
+                    else wait_lgkm<HP>();                // xb has landed
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, HP * CT>([&](auto KC) {
+                        constexpr int k = decltype(KC)::value, pt = k / CT, ct = k % CT;
+                        acc[HP + pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xb[pt], acc[HP + pt][ct], 0, 0, 0);
+                        if constexpr (k < CT) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (issued) {
+                                if constexpr (wrap) fetch_w1(std::integral_constant<int, 0>{}, KC, true, w[nxt]);
+                                else fetch_w1(std::integral_constant<int, i + 1>{}, KC, false, w[nxt]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
                 if (!wrap || !last_tap) {
                     issued = true;
                     if constexpr (wrap) {
@@ -435,12 +467,15 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 if (!issued) wait_lgkm<0>();
                 else wait_lgkm<HP + CT>();               // xb has landed
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ALT != 7) {
 #pragma unroll
                 for (int pt = 0; pt < HP; pt++)
 #pragma unroll
                     for (int ct = 0; ct < CT; ct++)
                         acc[HP + pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xb[pt], acc[HP + pt][ct], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (s == G::SPT - 1) t++;
             });
         };

@@ -196,18 +196,21 @@ class ChessModel(object):
     (policy f32 [B,1968], value f32 [B]) CUDA tensors out.
     """
 
-    # precision modes of the fused HIP trunk (dtype float16):
-    #   "f16"    one fp16 MFMA per product, fp32 accumulation and skip stream.  Within 1e-3 of an fp32
-    #            evaluation for Keras-initialised and lightly trained towers; a sharp tower (peaked
-    #            policy, values near +-1, unit-gain layers) is off by up to ~2e-2
-    #            (profiles/r03/tower_sharp_probe*.json).
-    #   "f16x3"  every operand carried as hi + lo fp16 pairs, three MFMAs per product (CRL_TRUNK_SPLIT):
-    #            within ~1e-5..1e-4 of fp32 whatever the weights, at ~3.3x the trunk time.
-    #   "auto"   decided per weight set when it is loaded: both modes evaluate a fixed probe set of
-    #            positions (random playouts by the rules kernels) and "f16" is kept only if it stays
-    #            within PROBE_TOL of "f16x3" on all of them.
+    # precision modes of the fused HIP trunk (dtype float16); errors are max |policy| / |value|
+    # differences to the fp32 oracle over 4096 real self-play positions, profiles/r03/tower_sharp_probe.json:
+    #   "f16"    one fp16 MFMA per product, fp32 accumulation and skip stream: BASELINE's "fp16 MFMA
+    #            inference", what bench.py times.  Keras-initialised towers: 4e-4 (6x64, 20x256) to
+    #            1.3e-3 (10x128, 10x256: a handful of positions in 4096 beyond 1e-3); a SHARP tower
+    #            (peaked policy, values spread over (-1, 1), unit-gain layers): 6e-3 .. 2.4e-2.
+    #   "f16x3"  every operand carried as a hi + lo fp16 pair, three MFMAs per product
+    #            (CRL_TRUNK_SPLIT): 3e-6 .. 8e-5 on every tower and weight set, the same as PyTorch's
+    #            fp32 convolutions, at 2.9x (64 filters), 3.1x (128) and 4.5x (256) the trunk time.
+    #   "auto"   (default: the 1e-3 bar of the drop-in contract comes first) decided per weight set
+    #            when it is loaded: both modes evaluate a fixed probe set of positions (random playouts
+    #            by the rules kernels) and "f16" is kept only if it stays within PROBE_TOL of "f16x3"
+    #            on all of them (the maximum over thousands of real positions is up to 1.7x the probe's).
     PRECISIONS = ("auto", "f16", "f16x3")
-    PROBE_TOL = 8e-4
+    PROBE_TOL = 6e-4
     PROBE_POSITIONS = 256
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
@@ -246,6 +249,7 @@ class ChessModel(object):
             self.net = net.cast_for_inference(self.device, self.dtype)
             self.blocks, self.filters = blocks, filters
             self._wtiles = None
+            self.graph_epoch += 1
         # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 64, 128 and
         # 256 filters in fp16
         self.fused = bool(self.want_fused and filters in (64, 128, 256) and self.dtype == torch.float16
@@ -316,14 +320,18 @@ class ChessModel(object):
                torch.cat([kp.reshape(2, F_), kv.reshape(1, F_)]).float(), torch.cat([bp, bv]).float())
         new = new + self._pack_dense(w)
         names = ("_wtiles", "_wtiles3", "_wbias", "_head_w", "_head_b", "_pol_wp", "_pol_bias", "_val_w1p", "_val_b1", "_val_w2")
-        if getattr(self, "_wtiles", None) is None:
-            for name, t in zip(names, new):
-                setattr(self, name, t.to(self.device).contiguous())
+        first = getattr(self, "_wtiles", None) is None
+        if first:
             self._pad_in = None
             self._pad_bits = None
-        else:                                                  # in place: captured graphs stay valid
-            for name, src in zip(names, new):
-                getattr(self, name).copy_(src)
+        for name, src in zip(names, new):
+            cur = None if first else getattr(self, name, None)
+            if cur is not None and cur.shape == src.shape:
+                cur.copy_(src)                                 # in place: captured graphs stay valid
+            else:
+                setattr(self, name, src.to(self.device).contiguous())
+                if cur is not None:
+                    self.graph_epoch += 1                      # a captured graph holds the old tensor
 
     @staticmethod
     def _pack_split(x, tiles, ksteps):
@@ -384,6 +392,32 @@ class ChessModel(object):
         if rc != 0:
             raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
         return (trunk[:b] if want_trunk else None), heads[:b]
+
+    def set_precision(self, precision):
+        """Switch the fused trunk's arithmetic mode on the loaded weights ("auto" re-runs the probe).
+        Engines holding a captured hipGraph notice through ``graph_epoch`` and capture again."""
+        if precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % (self.PRECISIONS,))
+        if not self.fused:
+            raise RuntimeError("precision modes belong to the fused HIP trunk")
+        self.precision_requested = precision
+        self._pack_fused(self.weights)           # the image of the other mode may not exist yet
+        self._resolve_precision()
+        return self.precision
+
+    def probe_error(self):
+        """max |policy| and |value| difference between the "f16" and "f16x3" modes on the probe
+        positions (the latter is within ~1e-4 of fp32): how far the fast mode is from the reference
+        arithmetic on THESE weights.  Packs both images for the measurement, leaves the mode as it was."""
+        keep_req, keep = self.precision_requested, self.precision
+        self.precision_requested = "auto"
+        self._pack_fused(self.weights)
+        planes = _probe_bitplanes(self.device, self.PROBE_POSITIONS)
+        pa, va = self._forward_fused(planes, precision="f16")
+        pb, vb = self._forward_fused(planes, precision="f16x3")
+        self.precision_requested, self.precision = keep_req, keep
+        return {"positions": int(planes.shape[0]), "dpolicy_max": float((pa - pb).abs().max()),
+                "dvalue_max": float((va - vb).abs().max())}
 
     def _resolve_precision(self):
         """Fix ``self.precision`` for the weights just packed.  "auto": evaluate the probe positions in

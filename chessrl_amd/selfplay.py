@@ -352,6 +352,10 @@ def main(argv=None):
                         help="overlap the rounds: freed slots take the next round's games while a round's "
                              "long games finish; a round is trained on as soon as its last game ends and "
                              "the games under way continue on the new weights")
+    parser.add_argument("--precision", choices=["auto", "f16", "f16x3"], default="auto",
+                        help="arithmetic of the fused HIP tower: 'f16' = one fp16 MFMA per product (fastest; "
+                             "1e-3 of fp32 only for soft nets), 'f16x3' = split operands, fp32-grade, ~3x the "
+                             "tower time, 'auto' = f16 where a probe shows it within the bar, else f16x3")
     parser.add_argument("--numpy-promotion", choices=["auto", "nep50", "legacy"], default="auto",
                         help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87): 'legacy' = the float64 "
                              "product of the reference's pinned numpy 1.17.2, 'nep50' = the float32 product "
@@ -376,7 +380,7 @@ def main(argv=None):
     path = get_model_path(args.model_dir)
     weights = path if os.path.exists(path) else None
     model = ChessModel(compile_model=not args.no_train, weights=weights, blocks=args.blocks,
-                       filters=args.filters, device="cuda:%d" % local, seed=args.seed)
+                       filters=args.filters, device="cuda:%d" % local, seed=args.seed, precision=args.precision)
     per_rank = (args.games + world - 1) // world
     parallel = args.parallel or min(per_rank, 4096)
     allrecs = []

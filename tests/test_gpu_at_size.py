@@ -94,12 +94,12 @@ def _open_with_random_plies(eng, seed, max_plies):
         eng.ctx.push_moves(pick)
 
 
-def _one_move_at_size(G, sims, blocks, filters, seed):
+def _one_move_at_size(G, sims, blocks, filters, seed, precision="f16"):
     from chessrl_amd import _lib
     from chessrl_amd.engine import LockstepEngine, choose_children
     from chessrl_amd.model import ChessModel
-    model = ChessModel(blocks=blocks, filters=filters, seed=seed)
-    assert model.fused
+    model = ChessModel(blocks=blocks, filters=filters, seed=seed, precision=precision)
+    assert model.fused and model.precision == precision
     eng = LockstepEngine(model, n_games=G, max_sims=sims, max_plies=512)
     eng.reset()
     _open_with_random_plies(eng, seed, 11)
@@ -173,4 +173,25 @@ def test_c3_size_one_move_properties():
     assert a["depth"] > 2.0
     print("C3 one move: mean depth %.2f, mean branching %.1f, terminal hits %d" % (
         a["depth"], a["branch"], a["terminal"]))
+    torch.cuda.empty_cache()
+
+
+def test_c5_size_one_move_properties():
+    """BASELINE config C5 (one GPU's shard): 4096 games, 800 sims/move, the 20-block/256-filter
+    tower, fp16 MFMA inference -- 1600 launches of the 256-filter trunk kernel at two boards per
+    workgroup under the same invariants."""
+    a = _one_move_at_size(4096, 800, 20, 256, seed=5, precision="f16")
+    assert a["depth"] > 2.0
+    print("C5 one move: mean depth %.2f, mean branching %.1f, terminal hits %d" % (
+        a["depth"], a["branch"], a["terminal"]))
+    torch.cuda.empty_cache()
+
+
+def test_c3_size_one_move_in_split_precision_and_the_reference_network():
+    """The split-precision trunk (f16x3: three MFMAs per product) at C3 size, and the network the
+    reference itself builds (model.py:33-37: 10 blocks x 256 filters) at 2048 games x 200 sims."""
+    a = _one_move_at_size(4096, 800, 10, 128, seed=3, precision="f16x3")
+    assert a["depth"] > 2.0
+    b = _one_move_at_size(2048, 200, 10, 256, seed=4, precision="f16")
+    print("C3 f16x3: depth %.2f; 10x256: depth %.2f" % (a["depth"], b["depth"]))
     torch.cuda.empty_cache()

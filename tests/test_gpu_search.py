@@ -261,47 +261,22 @@ def test_search_then_advance_matches_oracle_game():
 
 
 # Tower bar (north_star): |policy| and |value| within 1e-3 of the fp32 reference on the same weights.
-# Asserted at 1e-3, no exceptions, for every BASELINE tower size on the two kinds of weights the
-# product ever runs: Keras-default random init (what bench.py times) and weights the product's own
-# trainer produced (non-identity BatchNorm statistics, kernels and biases as training leaves them).
-# Measured on MI355X, fused fp16 trunk: default init 3.2e-4 (6x64), 6.1e-4 (10x128), 4.0e-4
-# (20x256); trained 2e-6, 3e-7, 2e-7 (the l2(0.01) of model.py:34 makes trained towers contractive:
-# BN gains gamma/sigma average 0.7-1.2 per layer, so rounding errors shrink with depth instead of
-# compounding; tools/tower_trained_probe.py).
-_TRAINED = {}
+# The full-size statement -- >= 4096 real self-play positions, every tower size, default-init and
+# SHARP weights, what precision="auto" picks -- is tests/test_gpu_tower.py.  Here: 30 boards (not a
+# multiple of 4: the padding path) through the engine's in-place path and the Keras-style predict()
+# surface, in f32 (PyTorch-ROCm) and f16 (fused trunk), on the same two kinds of weights.  (Round 2
+# had a "trained" leg: 3 epochs on 32 games give a collapsed net -- uniform policy, value ~ 0 -- on
+# which any error is invisible; it is replaced by the calibrated sharp net.)
+def _sharp_weights(blocks, filters):
+    games = random_prefix_games(64, 120, seed=19)
+    planes = np.stack([encoder_oracle.get_game_state(g) for g in games])
+    return tower_oracle.calibrated_weights(blocks, filters, planes, seed=7)
 
 
-def _trained_weights(blocks, filters):
-    """Weights of a (blocks, filters) tower after 3 epochs of the product's trainer on 32 quick
-    self-play games (played once per session by a 6x64 net)."""
-    from chessrl_amd.dataset import DatasetGame
-    from chessrl_amd.model import ChessModel
-    from chessrl_amd.netencoder import DataGameSequence
-    from chessrl_amd.selfplay import SelfPlayRunner
-    if "games" not in _TRAINED:
-        run = SelfPlayRunner(ChessModel(blocks=6, filters=64, seed=1), 32, 16, seed=3, noise=True,
-                             total_games=32, max_plies=1024)
-        _TRAINED["games"] = run.run()
-        run.close()
-    key = (blocks, filters)
-    if key not in _TRAINED:
-        model = ChessModel(compile_model=True, blocks=blocks, filters=filters, seed=2)
-        np.random.seed(1)
-        gen = DataGameSequence(DatasetGame(list(_TRAINED["games"])), batch_size=1, random_flips=.1)
-        hist = model.train_generator(gen, epochs=3)
-        assert hist[-1]["loss"] < hist[0]["loss"]
-        w = model.weights
-        gains = np.concatenate([np.asarray(w[k]) / np.sqrt(np.asarray(w[k[:-6] + ".var"]) + 1e-3)
-                                for k in w if k.endswith(".gamma")])
-        assert gains.max() - gains.min() > 0.5                 # BatchNorm is far from the identity
-        _TRAINED[key] = w
-    return _TRAINED[key]
-
-
-def _tower_errors(w, dtype, n_boards=30):
+def _tower_errors(w, dtype, n_boards=30, precision="auto"):
     from chessrl_amd.engine import LockstepEngine
     from chessrl_amd.model import ChessModel
-    model = ChessModel(weights=w, dtype=getattr(torch, dtype))
+    model = ChessModel(weights=w, dtype=getattr(torch, dtype), precision=precision)
     games = random_prefix_games(n_boards, 80, seed=9)           # 30: not a multiple of 4 (padding path)
     eng = LockstepEngine(model, n_games=n_boards, max_sims=4, use_graph=False)
     eng.load_moves([move_ids(g) for g in games])
@@ -315,13 +290,17 @@ def _tower_errors(w, dtype, n_boards=30):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
-@pytest.mark.parametrize("weights", ["keras_default_init", "trained"])
+@pytest.mark.parametrize("weights", ["keras_default_init", "sharp"])
 @pytest.mark.parametrize("blocks,filters", [(2, 32), (6, 64), (10, 128), (20, 256)])
 def test_tower_within_1e3_of_fp32_oracle(blocks, filters, weights, dtype):
     w = (tower_oracle.init_weights(blocks, filters, seed=4) if weights == "keras_default_init"
-         else _trained_weights(blocks, filters))
+         else _sharp_weights(blocks, filters))
     model, eng, planes, (pol, val), (epol, eval_), dp, dv = _tower_errors(w, dtype)
     assert model.fused == (filters in (64, 128, 256) and dtype == "float16")
+    if model.fused and weights == "sharp":       # precision="auto": the split mode wherever one MFMA per product is not enough
+        assert model.precision == "f16x3"
+    if weights == "sharp":
+        assert float(epol.max()) > 0.2 and float(eval_.abs().max()) > 0.5
     print("tower %dx%d %s %s fused=%d: max|dpolicy|=%.3g max|dvalue|=%.3g" %
           (blocks, filters, weights, dtype, model.fused, dp, dv))
     assert dp <= 1e-3 and dv <= 1e-3, (dp, dv)
@@ -355,10 +334,14 @@ STRESS_FP16_BOUND = {
 @pytest.mark.parametrize("blocks,filters", sorted(STRESS_FP16_BOUND))
 def test_fp16_trunk_drift_under_random_batchnorm_statistics_is_bounded(blocks, filters):
     w = tower_oracle.init_weights(blocks, filters, seed=4, randomize_bn=True)
-    model, eng, _, _, _, dp, dv = _tower_errors(w, "float16")
+    model, eng, _, _, _, dp, dv = _tower_errors(w, "float16", precision="f16")
     ptol, vtol = STRESS_FP16_BOUND[(blocks, filters)]
     print("stress %dx%d: max|dpolicy|=%.3g max|dvalue|=%.3g (bounds %g / %g)" % (blocks, filters, dp, dv, ptol, vtol))
-    assert model.fused and dp <= ptol and dv <= vtol
+    assert model.fused and model.precision == "f16" and dp <= ptol and dv <= vtol
+    eng.close()
+    # the split mode of the fused trunk meets the bar on the same statistics
+    model, eng, _, _, _, dp, dv = _tower_errors(w, "float16", precision="f16x3")
+    assert model.fused and model.precision == "f16x3" and dp <= 1e-3 and dv <= 1e-3
     eng.close()
     # the f32 path stays within 1e-3 (measured 1e-5) on the same statistics
     model, eng, _, _, _, dp, dv = _tower_errors(w, "float32")

@@ -1,0 +1,120 @@
+"""GPU: the north_star's tower bar -- policy and value within 1e-3 of the fp32 reference network on
+the same weights (model.py:31-63 runs fp32) -- on >= 4096 positions harvested from REAL self-play
+(openings, middle games, long endgames, positions after promotions), for every tower size of
+BASELINE.json plus the network the reference itself builds (10 x 256, model.py:33-37), and on two
+kinds of weights:
+
+* ``keras_default_init``: what bench.py times (random-init nets);
+* ``sharp``: a net whose outputs are SENSITIVE to its input, the way a trained net's are
+  (oracle/tower_oracle.calibrated_weights: BatchNorm statistics calibrated on real positions so
+  every layer has unit gain, policy Dense scaled to peaked distributions, value spread over
+  (-1, 1)).  The test asserts that sharpness (max p > 0.3, |v| > 0.5, values spread), so it cannot
+  pass on a constant-output net: on such weights a near-uniform policy hides any error.
+
+The fused trunk has two arithmetic modes: "f16" (one fp16 MFMA per product: BASELINE's "fp16 MFMA
+inference", what bench.py times) and "f16x3" (operands carried as hi + lo fp16 pairs, three MFMAs
+per product: fp32-grade).  Measured on MI355X (profiles/r03/tower_sharp_probe.json): f16 is 4e-4 ..
+1.3e-3 off on default-init nets (a handful of the 4096 positions beyond 1e-3 at 10x128 and 10x256)
+and 6e-3 .. 2.4e-2 off on the sharp ones; f16x3 is within 1e-4 on all.  ``precision="auto"`` (the
+product's default) must therefore pick a mode that meets 1e-3 on the real positions -- asserted here
+for what it picks, whatever that is -- and must pick f16x3 for the sharp nets; f16 must NOT meet the
+bar there (negative control: the comparison is able to fail), and on default-init nets f16 is
+asserted at the bound it was measured at (2e-3), the figure bench.py's mode carries.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tower_oracle
+from tests.util import encode_prefixes, selfplay_position_prefixes
+
+pytestmark = pytest.mark.gpu
+N_POSITIONS = 4096
+_CACHE = {}
+
+
+def _positions():
+    if "x" not in _CACHE:
+        from chessrl_amd.model import ChessModel
+        prefixes, info = selfplay_position_prefixes(N_POSITIONS)
+        assert len(prefixes) == N_POSITIONS
+        # real games: openings, long endgames and positions after promotions are all in the sample
+        assert info["opening_lt_20"] > 50 and info["late_ge_150"] > 500 and info["after_a_promotion"] > 100
+        x_bits, planes = encode_prefixes(ChessModel(blocks=2, filters=64, precision="f16"), prefixes)
+        assert len(np.unique(planes.reshape(N_POSITIONS, -1), axis=0)) > 0.9 * N_POSITIONS
+        _CACHE["x"], _CACHE["planes"], _CACHE["info"] = x_bits, planes, info
+    return _CACHE["x"], _CACHE["planes"]
+
+
+def _errors(pol, val, epol, eval_):
+    dp = (pol.cpu() - epol).abs().max(1).values.numpy()
+    dv = (val.cpu() - eval_).abs().numpy()
+    return dp, dv
+
+
+@pytest.mark.parametrize("weights", ["keras_default_init", "sharp"])
+@pytest.mark.parametrize("blocks,filters", [(6, 64), (10, 128), (10, 256), (20, 256)])
+def test_tower_within_1e3_on_real_selfplay_positions(blocks, filters, weights):
+    from chessrl_amd.model import ChessModel
+    x_bits, planes = _positions()
+    if weights == "sharp":
+        w = tower_oracle.calibrated_weights(blocks, filters, planes[:512], seed=7)
+    else:
+        w = tower_oracle.init_weights(blocks, filters, seed=4)
+    epol, eval_ = tower_oracle.forward(w, planes)
+    if weights == "sharp":
+        # the net is sensitive: peaked policies, values spread over (-1, 1), different per position
+        assert float(epol.max()) > 0.3 and float(epol.max(1).values.mean()) > 0.1
+        assert float(eval_.abs().max()) > 0.5 and float(eval_.std()) > 0.3
+    model = ChessModel(weights=w)                                   # precision="auto"
+    assert model.fused and model.precision_probe["chosen"] == model.precision
+    pol, val = model(x_bits)
+    dp, dv = _errors(pol, val, epol, eval_)
+    print("tower %dx%d %s: auto -> %s (probe %.2e / %.2e); %d real positions: |dpolicy| max %.2e p99.9 %.2e, "
+          "|dvalue| max %.2e p99.9 %.2e" % (blocks, filters, weights, model.precision,
+                                            model.precision_probe["dpolicy_max"], model.precision_probe["dvalue_max"],
+                                            N_POSITIONS, dp.max(), np.quantile(dp, 0.999), dv.max(), np.quantile(dv, 0.999)))
+    assert dp.max() <= 1e-3 and dv.max() <= 1e-3, (model.precision, dp.max(), dv.max())
+    if weights == "sharp":
+        assert model.precision == "f16x3"
+        # negative control: one fp16 MFMA per product does NOT meet the bar on this net -- the
+        # comparison above is able to fail; bounded drift (measured 6e-3 .. 2.4e-2)
+        p16, v16 = model._forward_fused(x_bits, precision="f16")
+        dp16, dv16 = _errors(p16, v16, epol, eval_)
+        assert max(dp16.max(), dv16.max()) > 1e-3 and max(dp16.max(), dv16.max()) < 0.1
+        # the split mode is fp32-grade, far inside the bar
+        assert dp.max() <= 2e-4 and dv.max() <= 2e-4
+    else:
+        # the mode bench.py times (--precision f16) on these random-init weights
+        p16, v16 = model._forward_fused(x_bits, precision="f16")
+        dp16, dv16 = _errors(p16, v16, epol, eval_)
+        print("    f16 on the same weights: |dpolicy| max %.2e, |dvalue| max %.2e p99.9 %.2e, %d of %d positions beyond 1e-3"
+              % (dp16.max(), dv16.max(), np.quantile(dv16, 0.999), int(((dp16 > 1e-3) | (dv16 > 1e-3)).sum()), N_POSITIONS))
+        assert dp16.max() <= 1e-3 and dv16.max() <= 2e-3 and np.quantile(dv16, 0.99) <= 1e-3
+
+
+def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
+    """``precision`` pins a mode; "auto" re-decides when new weights are loaded in place (training
+    rounds) and says so through ``graph_epoch`` so that a LockstepEngine re-captures its hipGraph."""
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    _, planes = _positions()
+    easy = tower_oracle.init_weights(2, 64, seed=4)
+    sharp = tower_oracle.calibrated_weights(2, 64, planes[:256], seed=7)
+    for mode in ("f16", "f16x3"):
+        assert ChessModel(weights=sharp, precision=mode).precision == mode
+    with pytest.raises(ValueError):
+        ChessModel(weights=easy, precision="fp64")
+    model = ChessModel(weights=easy)                                # 2x64 default init: f16 is far inside the bar
+    assert model.precision == "f16" and model.graph_epoch == 0
+    eng = LockstepEngine(model, n_games=8, max_sims=8)
+    eng.reset()
+    eng.search(8)
+    first = eng._graph
+    model.load_dict(sharp)                                          # in place, under the captured graph
+    assert model.precision == "f16x3" and model.graph_epoch == 1
+    eng.search(8)
+    assert eng._graph is not first                                  # re-captured with the split kernel
+    rc = eng.root_children()
+    assert (rc["root_visits"] == 9).all()
+    eng.close()
