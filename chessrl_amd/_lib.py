@@ -52,7 +52,7 @@ SYMBOLS = [
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
     "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
     "crl_trunk_forward_bitplanes", "crl_trunk_forward_x", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
-    "crl_heads_forward_legal",
+    "crl_heads_forward_legal", "crl_heads_set_sliced_max",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -183,8 +183,9 @@ def lib():
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]
-    L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
-    L.crl_heads_forward_legal.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_forward_legal.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_set_sliced_max.argtypes = [i32]
     L.crl_set_policy_format.argtypes = [vp, i32]
     L.crl_eval_labels.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]

@@ -675,54 +675,89 @@ int crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_b
                          n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
 }
 
-int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
-                      const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
-                      const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
-                      const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32)
+// Batches of at most g_sliced_max boards run the heads as label slices x board blocks + a normalising
+// pass (csrc/heads.hpp: k_heads_sliced, k_policy_normalise) when the caller hands over the scratch for
+// the slice statistics; larger ones the one-pass kernels (every CU already has a workgroup there).
+static std::atomic<int> g_sliced_max{1024};
+
+int crl_heads_set_sliced_max(int boards)
 {
-    if (!dev_head_act_f32 || n_boards < 1 || !dev_policy_wp_f16 || !dev_policy_bias_f32 || !dev_policy_out_f32 ||
-        (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
-        return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward: bad argument");
+    g_sliced_max.store(boards < 0 ? 0 : boards);
+    return CRL_OK;
+}
+
+static int heads_forward(void *hip_stream, const void *act, int n_boards, const void *pol_wp, const void *pol_bias,
+                         const void *val_w1p, const void *val_b1, const void *val_w2b2, const uint16_t *labels,
+                         const int32_t *counts, void *pol_out, void *val_out, void *scratch, bool legal,
+                         const char *who)
+{
+    if (!act || n_boards < 1 || !pol_wp || !pol_bias || !pol_out || (legal && (!labels || !counts)) ||
+        (val_out && (!val_w1p || !val_b1 || !val_w2b2)))
+        return fail(nullptr, CRL_ERR_ARG, who);
+    hipStream_t st = (hipStream_t)hip_stream;
     const unsigned blocks = (unsigned)((n_boards + 15) / 16);
-    hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, (hipStream_t)hip_stream,
-                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
-                       (const float *)dev_policy_bias_f32, (float *)dev_policy_out_f32);
-    if (dev_value_out_f32)
-        hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
-                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,
-                           (const float *)dev_value_b1_f32, (const float *)dev_value_w2b2_f32,
-                           (float *)dev_value_out_f32);
+    if (scratch && n_boards <= g_sliced_max.load()) {
+        const dim3 grid(crl_heads::N_SLICES + (val_out ? 1 : 0), blocks);
+        if (legal) {
+            hipLaunchKernelGGL(crl_heads::k_heads_sliced<true>, grid, dim3(256), 0, st, (const float *)act, n_boards,
+                               (const unsigned char *)pol_wp, (const float *)pol_bias, (float *)pol_out, (float2 *)scratch,
+                               (const unsigned short *)labels, (const int *)counts, (const unsigned char *)val_w1p,
+                               (const float *)val_b1, (const float *)val_w2b2, (float *)val_out);
+            hipLaunchKernelGGL(crl_heads::k_policy_normalise<true>, dim3((n_boards + 3) / 4), dim3(256), 0, st,
+                               (float *)pol_out, (const float2 *)scratch, n_boards, (const int *)counts);
+        } else {
+            hipLaunchKernelGGL(crl_heads::k_heads_sliced<false>, grid, dim3(256), 0, st, (const float *)act, n_boards,
+                               (const unsigned char *)pol_wp, (const float *)pol_bias, (float *)pol_out, (float2 *)scratch,
+                               (const unsigned short *)nullptr, (const int *)nullptr, (const unsigned char *)val_w1p,
+                               (const float *)val_b1, (const float *)val_w2b2, (float *)val_out);
+            hipLaunchKernelGGL(crl_heads::k_policy_normalise<false>, dim3((n_boards + 3) / 4), dim3(256), 0, st,
+                               (float *)pol_out, (const float2 *)scratch, n_boards, (const int *)nullptr);
+        }
+    } else {
+        if (legal) {
+            auto kern = crl_heads::k_policy_head<1, true>;
+            hipError_t ea = allow_big_lds((const void *)kern, crl_heads::LEGAL_LDS_BYTES);
+            if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), crl_heads::LEGAL_LDS_BYTES, st,
+                               (const float *)act, n_boards, (const unsigned char *)pol_wp, (const float *)pol_bias,
+                               (float *)pol_out, (const unsigned short *)labels, (const int *)counts);
+        } else {
+            hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, st,
+                               (const float *)act, n_boards, (const unsigned char *)pol_wp, (const float *)pol_bias,
+                               (float *)pol_out);
+        }
+        if (val_out)
+            hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, st,
+                               (const float *)act, n_boards, (const unsigned char *)val_w1p, (const float *)val_b1,
+                               (const float *)val_w2b2, (float *)val_out);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
+}
+
+int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                      const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                      const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                      const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32,
+                      void *dev_scratch_f32)
+{
+    return heads_forward(hip_stream, dev_head_act_f32, n_boards, dev_policy_wp_f16, dev_policy_bias_f32,
+                         dev_value_w1p_f16, dev_value_b1_f32, dev_value_w2b2_f32, nullptr, nullptr,
+                         dev_policy_out_f32, dev_value_out_f32, dev_scratch_f32, false, "crl_heads_forward: bad argument");
 }
 
 int crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int n_boards,
                             const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
                             const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
                             const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
-                            const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32)
+                            const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32,
+                            void *dev_scratch_f32)
 {
-    if (!dev_head_act_f32 || n_boards < 1 || !dev_policy_wp_f16 || !dev_policy_bias_f32 || !dev_priors_out_f32 ||
-        !dev_labels || !dev_counts ||
-        (dev_value_out_f32 && (!dev_value_w1p_f16 || !dev_value_b1_f32 || !dev_value_w2b2_f32)))
-        return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward_legal: bad argument");
-    auto kern = crl_heads::k_policy_head<1, true>;
-    hipError_t ea = allow_big_lds((const void *)kern, crl_heads::LEGAL_LDS_BYTES);
-    if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
-    const unsigned blocks = (unsigned)((n_boards + 15) / 16);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), crl_heads::LEGAL_LDS_BYTES, (hipStream_t)hip_stream,
-                       (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_policy_wp_f16,
-                       (const float *)dev_policy_bias_f32, (float *)dev_priors_out_f32,
-                       (const unsigned short *)dev_labels, (const int *)dev_counts);
-    if (dev_value_out_f32)
-        hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, (hipStream_t)hip_stream,
-                           (const float *)dev_head_act_f32, n_boards, (const unsigned char *)dev_value_w1p_f16,
-                           (const float *)dev_value_b1_f32, (const float *)dev_value_w2b2_f32,
-                           (float *)dev_value_out_f32);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
-    return CRL_OK;
+    return heads_forward(hip_stream, dev_head_act_f32, n_boards, dev_policy_wp_f16, dev_policy_bias_f32,
+                         dev_value_w1p_f16, dev_value_b1_f32, dev_value_w2b2_f32, dev_labels, dev_counts,
+                         dev_priors_out_f32, dev_value_out_f32, dev_scratch_f32, true,
+                         "crl_heads_forward_legal: bad argument");
 }
 
 static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, int channels, bool forward)

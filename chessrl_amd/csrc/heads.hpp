@@ -245,4 +245,174 @@ __global__ __launch_bounds__(64) void k_value_head(const float *__restrict__ act
     if (valid && q == 0) value[board] = tanhf(z + w2[256]);    // b2 from memory: weights may change under a captured graph
 }
 
+// ---- the same two heads for SMALL batches: label slices x board blocks ------------------------------
+// k_policy_head gives every workgroup 16 boards and ALL 2048 labels: a batch of 512 boards is 32
+// workgroups, each pulling the whole 1-MiB packed kernel through one CU (14 us: a fifth of a C2
+// step, with 224 CUs idle).  Here the labels are cut into N_SLICES = 8 slices of 256: the grid is
+// (9, board blocks) workgroups of 4 waves, slice s < 8 computing the logits of labels [256 s, +256)
+// for its 16 boards (128 KiB of the packed kernel; a wave owns 4 tiles of 16 labels) and slice 8
+// being the VALUE head of those boards (k_value_head's arithmetic, one wave), so the value no longer
+// costs a launch of its own.  A softmax over slices needs two passes; pass 1 leaves
+//     logits   (FULL: policy[board][label], LEGAL: priors[board][j] for the legal labels of the slice)
+//     stats    [board][slice] = (m = max logit of the slice, s = sum exp(logit - m) over the slice)
+// and pass 2 (k_policy_normalise) turns every stored logit l into  exp(l - M) / S  with
+//     M = max_k m_k,   S = sum_k s_k exp(m_k - M)   (k = 0..7 in that order: reproducible).
+// FULL and LEGAL run the same arithmetic on the same numbers: identical values, as in the one-pass
+// kernel.  The values differ from the one-pass kernel's in the last bits (another summation order).
+constexpr int N_SLICES = 8;
+constexpr int SLICE_LABELS = N_LABELS_PAD / N_SLICES;     // 256
+constexpr int SL_STRIDE = SLICE_LABELS + 4;               // LDS row of a board's slice logits
+
+template <bool LEGAL>
+__global__ __launch_bounds__(256) void k_heads_sliced(const float *__restrict__ act, int n_boards,
+                                                      const unsigned char *__restrict__ wp,    // packed fp16 policy kernel
+                                                      const float *__restrict__ bias,          // [2048], pad = -1e30
+                                                      float *__restrict__ policy,              // logits out (FULL [n][1968] / LEGAL [n][256])
+                                                      float2 *__restrict__ stats,              // [n][N_SLICES]
+                                                      const unsigned short *__restrict__ labels,
+                                                      const int *__restrict__ counts,
+                                                      const unsigned char *__restrict__ w1p,   // value head (may be null: no value wanted)
+                                                      const float *__restrict__ b1, const float *__restrict__ w2,
+                                                      float *__restrict__ value)
+{
+    __shared__ float s_max[4][16], s_sum[4][16];
+    __shared__ __attribute__((aligned(16))) float s_l[LEGAL ? 16 * SL_STRIDE : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int slice = blockIdx.x, board = blockIdx.y * 16 + r;
+    const bool valid = board < n_boards;
+    if (slice == N_SLICES) {
+        // ---- value head of this board block: tanh(relu(h . W1 + b1) . W2 + b2), one wave
+        if (wave != 0 || !value) return;
+        const float *row = act + (size_t)board * ACT + 128;
+        half8 hhi[2], hlo[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
+        const half8 *wf = reinterpret_cast<const half8 *>(w1p) + lane;
+        float z = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 16; jt++) {
+            f32x4h d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const half8 ahi = wf[((jt * 2 + s) * 2 + 0) * 64], alo = wf[((jt * 2 + s) * 2 + 1) * 64];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hhi[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, hhi[s], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hlo[s], d, 0, 0, 0);
+            }
+            const f32x4h bv = *reinterpret_cast<const f32x4h *>(b1 + jt * 16 + 4 * q);
+            const f32x4h wv = *reinterpret_cast<const f32x4h *>(w2 + jt * 16 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; j++) z += fmaxf(d[j] + bv[j], 0.f) * wv[j];
+        }
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        if (valid && q == 0) value[board] = tanhf(z + w2[256]);
+        return;
+    }
+    // ---- policy logits of labels [256 slice + 64 wave, +64) for the 16 boards
+    half8 hhi[4], hlo[4];
+    {
+        const float *row = act + (size_t)board * ACT;
+#pragma unroll
+        for (int s = 0; s < 4; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
+    }
+    const int tile0 = slice * 16 + wave * 4;
+    const half8 *wf = reinterpret_cast<const half8 *>(wp) + (size_t)tile0 * (4 * 2 * 64) + lane;
+    half8 a[4][8];                                       // all four tiles in flight at once
+    f32x4h acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int f = 0; f < 8; f++) a[t][f] = wf[(t * 8 + f) * 64];
+        acc[t] = *reinterpret_cast<const f32x4h *>(bias + (tile0 + t) * 16 + 4 * q);      // bias = C operand
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * s], hhi[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * s + 1], hhi[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * s], hlo[s], acc[t], 0, 0, 0);
+        }
+    // slice statistics of board r: max, then sum of exponentials, over 4 waves x 4 tiles x 16 labels
+    float m = acc[0][0];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) m = fmaxf(m, acc[t][j]);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (q == 0) s_max[wave][r] = m;
+    if constexpr (LEGAL) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            *reinterpret_cast<f32x4h *>(s_l + r * SL_STRIDE + wave * 64 + t * 16 + 4 * q) = acc[t];
+    }
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(s_max[0][r], s_max[1][r]), fmaxf(s_max[2][r], s_max[3][r]));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) sum += __expf(acc[t][j] - mx);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (q == 0) s_sum[wave][r] = sum;
+    __syncthreads();
+    if (wave == 0 && q == 0 && valid)
+        stats[(size_t)board * N_SLICES + slice] = make_float2(mx, ((s_sum[0][r] + s_sum[1][r]) + s_sum[2][r]) + s_sum[3][r]);
+    if constexpr (LEGAL) {
+        const int b = tid >> 4, l = tid & 15;            // 16 threads per board
+        const int gb = blockIdx.y * 16 + b;
+        if (gb < n_boards) {
+            int cnt = counts[gb];
+            cnt = cnt < 0 ? 0 : (cnt > LEGAL_STRIDE ? LEGAL_STRIDE : cnt);
+            for (int j = l; j < cnt; j += 16) {
+                const int lab = labels[(size_t)gb * LEGAL_STRIDE + j] & (N_LABELS_PAD - 1);
+                if ((lab >> 8) == slice) policy[(size_t)gb * LEGAL_STRIDE + j] = s_l[b * SL_STRIDE + (lab & 255)];
+            }
+        }
+    } else if (valid) {
+        float *out = policy + (size_t)board * N_LABELS + tile0 * 16 + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if ((tile0 + t) * 16 < N_LABELS)             // 1968 = 123 tiles: whole tiles only
+                *reinterpret_cast<f32x4h *>(out + t * 16) = acc[t];
+    }
+}
+
+// pass 2: every stored logit l of a board becomes exp(l - M) / S.  One wave per board.
+template <bool LEGAL>
+__global__ __launch_bounds__(256) void k_policy_normalise(float *__restrict__ policy, const float2 *__restrict__ stats,
+                                                          int n_boards, const int *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63, board = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (board >= n_boards) return;
+    float2 st[N_SLICES];
+#pragma unroll
+    for (int k = 0; k < N_SLICES; k++) st[k] = stats[(size_t)board * N_SLICES + k];
+    float M = st[0].x;
+#pragma unroll
+    for (int k = 1; k < N_SLICES; k++) M = fmaxf(M, st[k].x);
+    float S = 0.f;
+#pragma unroll
+    for (int k = 0; k < N_SLICES; k++) S += st[k].y * __expf(st[k].x - M);
+    const float inv = 1.0f / S;
+    if constexpr (LEGAL) {
+        int cnt = counts[board];
+        cnt = cnt < 0 ? 0 : (cnt > LEGAL_STRIDE ? LEGAL_STRIDE : cnt);
+        float *row = policy + (size_t)board * LEGAL_STRIDE;
+        for (int j = lane; j < cnt; j += 64) row[j] = __expf(row[j] - M) * inv;
+    } else {
+        f32x4h *row = reinterpret_cast<f32x4h *>(policy + (size_t)board * N_LABELS);     // 1968 floats = 492 quads, 16-byte aligned
+        for (int j = lane; j < N_LABELS / 4; j += 64) {
+            f32x4h v = row[j];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = __expf(v[e] - M) * inv;
+            row[j] = v;
+        }
+    }
+}
+
 }  // namespace crl_heads

@@ -93,8 +93,8 @@ struct Geo16 {
 // (ALT 2: in-kernel cycle stamps; ALT 3, 4, 5, 6, 7: timing-only builds without the weight staging, without
 // the per-tile barrier, without both, without the fragment reads from LDS, with NOTHING BUT the weight
 // staging, barriers and epilogues (no fragment reads, no MFMAs) -- harness diagnostics, WRONG
-// results, never dispatched.  ALT 8: correct results, the weight-fragment reads of the next sub-step
-// issued one by one between the MFMAs of half 1 instead of in one clump before them.)
+// results, never dispatched.  ALT 8: correct results, round 2's schedule: the weight-fragment reads of the
+// next sub-step issued in one clump before the MFMAs of half 1 instead of one by one between them.)
 // ALT = 0: every wave moves GL pieces of 1 KiB.  ALT = 1: the tile is moved by ONE half of the
 // workgroup -- waves 0-3 move even tiles, waves 4-7 odd tiles, 2 GL pieces each -- so that of the
 // two waves sharing a SIMD only one sits in the LDS-DMA issue queue after a barrier while the other
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
     static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2 || ALT == 7 || ALT == 8)), "pair publishing: even tile counts per layer");
+    static_assert(!SPLIT || ALT != 8, "the split-precision kernels run the production schedule");
     constexpr int GK = 3;                               // GROUP: taps (= tiles) per barrier
     constexpr int GRG = NB == 2 ? 4 : 3;                // GROUP: groups in the weight ring
     constexpr int GR = GK * GRG;                        // GROUP: ring slots
@@ -354,12 +355,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             }
             auto fetch_w1 = [&](auto IC, auto CC, bool next_tap, half8 (&dst)[CT]) {
                 constexpr int i = decltype(IC)::value, ct = decltype(CC)::value;
+                if constexpr (ALT == 7) return;
+                if constexpr (ALT == 6) { if (t > 1) return; }
                 constexpr int off = ct * 1024 + (i % G::SPT) * G::WPLANE + (PAIR ? 0 : (i / G::SPT) * G::TILE_BYTES);
                 dst[ct] = lds_read16_asm<off>(next_tap ? wv_nxt : wv[PAIR ? i / G::SPT : 0]);
             };
             auto fetch_w = [&](auto IC, bool next_tap, half8 (&dst)[CT]) {
-                if constexpr (ALT == 7) return;
-                if constexpr (ALT == 6) { if (t > 1) return; }
                 static_for<0, CT>([&](auto CC) { fetch_w1(IC, CC, next_tap, dst); });
             };
             if (first_tap) {
@@ -429,9 +430,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 // ---- half 1: position blocks [HP, PT); prefetch the next sub-step
                 constexpr bool wrap = i + 1 >= NS;
                 bool issued = false;
-                if constexpr (ALT == 8) {
-                    // the next sub-step's activation fragments before the wait as ever; its CT weight
-                    // fragments one by one behind the first CT MFMAs of this half
+                if constexpr (ALT != 8 && ALT != 7) {
+                    // the next sub-step's activation fragments before the wait; its CT weight fragments
+                    // one by one behind the first CT MFMAs of this half: a wave that issues all HP + CT
+                    // reads in one clump keeps its MFMAs waiting behind 6 KiB of LDS transfers, -1.1 ..
+                    // -1.6 % of kernel time at 128 and 256 filters (tools/ubench/trunk_r3.hip; ALT 8 = the
+                    // clumped schedule of round 2; same MFMA order, bit-identical results)
                     if (!wrap || !last_tap) {
                         issued = true;
                         if constexpr (wrap) fetch_xa(std::integral_constant<int, 0>{}, true);

@@ -246,19 +246,31 @@ class ChessModel(object):
         else:
             net = Tower(blocks, filters)
             net.load_keras_dict(weights)
-            self.net = net.cast_for_inference(self.device, self.dtype)
+            self.net = net.cast_for_inference(self.device, self._torch_dtype(filters, blocks))
             self.blocks, self.filters = blocks, filters
             self._wtiles = None
             self.graph_epoch += 1
         # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 64, 128 and
         # 256 filters in fp16
-        self.fused = bool(self.want_fused and filters in (64, 128, 256) and self.dtype == torch.float16
-                          and 1 + 2 * blocks <= 41)
+        self.fused = self._will_fuse(filters, blocks)
         if self.fused:
             self._pack_fused(weights)
             self._resolve_precision()
         else:
-            self.precision = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[self.dtype]
+            self.precision = {torch.float16: "f16", torch.bfloat16: "bf16",
+                              torch.float32: "f32"}[self._torch_dtype(filters, blocks)]
+
+    def _will_fuse(self, filters, blocks):
+        return bool(self.want_fused and filters in (64, 128, 256) and self.dtype == torch.float16
+                    and 1 + 2 * blocks <= 41)
+
+    def _torch_dtype(self, filters, blocks):
+        """dtype of the PyTorch-ROCm tower.  Where the fused HIP trunk does not apply (other filter
+        counts, fused=False) fp16 convolutions are only run when asked for by name (precision="f16");
+        "auto" and "f16x3" mean the 1e-3 bar holds whatever the weights, which there is fp32."""
+        if self.dtype == torch.float16 and not self._will_fuse(filters, blocks) and self.precision_requested != "f16":
+            return torch.float32
+        return self.dtype
 
     @staticmethod
     def _plane_order(F_):
@@ -454,10 +466,21 @@ class ChessModel(object):
         rc = _lib.lib().crl_heads_forward(
             vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), b,
             vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
-            vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(p.data_ptr()), vp(v.data_ptr() if v is not None else None))
+            vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(p.data_ptr()), vp(v.data_ptr() if v is not None else None),
+            vp(self._heads_scratch(b).data_ptr()))
         if rc != 0:
             raise _lib.HipLibraryError("crl_heads_forward failed (%d)" % rc)
         return p, v
+
+    def _heads_scratch(self, n_boards):
+        """Slice statistics of the small-batch heads (crl_heads_forward: float [n_boards][16]); one
+        buffer per batch size, kept, so that captured graphs hold a stable address."""
+        buf = self._scratch.get(n_boards) if hasattr(self, "_scratch") else None
+        if buf is None:
+            if not hasattr(self, "_scratch"):
+                self._scratch = {}
+            buf = self._scratch[n_boards] = torch.zeros((n_boards, 16), dtype=torch.float32, device=self.device)
+        return buf
 
     @property
     def accepts_legal_labels(self):
@@ -480,7 +503,8 @@ class ChessModel(object):
             vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), hp.shape[0],
             vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
             vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr), vp(counts_ptr),
-            vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None))
+            vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None),
+            vp(self._heads_scratch(hp.shape[0]).data_ptr()))
         if rc != 0:
             raise _lib.HipLibraryError("crl_heads_forward_legal failed (%d)" % rc)
 
@@ -548,7 +572,7 @@ class ChessModel(object):
             return self._forward_fused(planes)
         if planes.dtype == torch.int64:
             raise ValueError("plane bitboards are only understood by the fused HIP trunk")
-        x = planes.to(self.dtype).permute(0, 3, 1, 2)         # NHWC memory viewed as NCHW
+        x = planes.to(self.net.stem.weight.dtype).permute(0, 3, 1, 2)   # NHWC memory viewed as NCHW
         return self.net(x)
 
     @torch.no_grad()

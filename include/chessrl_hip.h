@@ -241,11 +241,12 @@ int  crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_
  * [tile 16][k-step 2][hi|lo][lane][8]: 64 KiB; b1 [256]; dev_value_w2b2_f32 [257] = w2 then b2 (in
  * memory, not by value: weights may be rewritten in place under a captured hipGraph).
  * dev_policy_out_f32: [n_boards][1968] probabilities; dev_value_out_f32: [n_boards] or NULL (the
- * value head is skipped: evaluations of S1 only choose the reply).  Stateless. */
+ * value head is skipped: evaluations of S1 only choose the reply).  Stateless (dev_scratch_f32: below). */
 int  crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
                        const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
                        const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
-                       const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32);
+                       const void *dev_value_w2b2_f32, void *dev_policy_out_f32, void *dev_value_out_f32,
+                       void *dev_scratch_f32);
 
 /* crl_heads_forward writing only what the search reads: dev_priors_out_f32 [n_boards][CRL_MAX_MOVES],
  * entry j of row b = softmax(...)[dev_labels[b][j]] for j < dev_counts[b] (the rest of the row is left
@@ -255,7 +256,16 @@ int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int
                              const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
                              const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
                              const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
-                             const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32);
+                             const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32,
+                             void *dev_scratch_f32);
+
+/* dev_scratch_f32 of the two calls above: float [n_boards][16] or NULL.  With it, batches of at most
+ * crl_heads_set_sliced_max boards (default 1024) run as label slices x board blocks (8 slices of 256
+ * labels, the value head as a ninth "slice": 9 x n_boards/16 workgroups instead of n_boards/16)
+ * followed by a normalising pass that reads the slice statistics left in the scratch -- a batch of
+ * 512 boards otherwise pulls the whole 1-MiB policy kernel through each of 32 CUs.  Same results for
+ * the two calls (bit for bit); the last bits differ from the one-pass form (summation order). */
+int  crl_heads_set_sliced_max(int boards);
 
 /* Batches of at most 512 boards (256 at 256 filters) give at most half of the 256 CUs a
  * workgroup; they run the same kernels with half the boards per workgroup and twice the

@@ -380,11 +380,14 @@ def test_fused_trunk_matches_pytorch_trunk_activations(filters, n_boards):
         assert (heads - heads_big).abs().max().item() <= 1e-5 * max(1.0, heads.abs().max().item())
 
 
+@pytest.mark.parametrize("sliced", [False, True])
 @pytest.mark.parametrize("n_boards", [5, 64, 1000])
-def test_mfma_dense_heads_match_the_fp32_dense_layers(n_boards):
+def test_mfma_dense_heads_match_the_fp32_dense_layers(n_boards, sliced):
     """crl_heads_forward (csrc/heads.hpp: Dense(1968)+softmax, Dense(256)-relu-Dense(1)-tanh on
     (hi, lo)-split fp16 MFMAs) against the same layers in torch fp32 on the same head activations,
-    incl. batches that are not a multiple of the 16-board blocks and the policy-only call."""
+    incl. batches that are not a multiple of the 16-board blocks and the policy-only call; in the
+    one-pass form and (scratch given: batches up to 1024 boards) as label slices + normalising pass
+    with the value head riding along."""
     import ctypes
     from chessrl_amd import _lib
     from chessrl_amd.model import ChessModel
@@ -401,13 +404,14 @@ def test_mfma_dense_heads_match_the_fp32_dense_layers(n_boards):
         ref_p = torch.softmax(n.policy_fc(hp[:, :128]), -1)
         ref_v = torch.tanh(n.value_fc2(F.relu(n.value_fc1(hp[:, 128:])))[:, 0])
     vp = ctypes.c_void_p
+    scratch = torch.full((n_boards + 3, 16), -7.0, device="cuda")
 
     def run(pol, val):
         rc = _lib.lib().crl_heads_forward(
             vp(torch.cuda.current_stream().cuda_stream), vp(hp.data_ptr()), n_boards,
             vp(model._pol_wp.data_ptr()), vp(model._pol_bias.data_ptr()), vp(model._val_w1p.data_ptr()),
             vp(model._val_b1.data_ptr()), vp(model._val_w2.data_ptr()), vp(pol.data_ptr()),
-            vp(val.data_ptr() if val is not None else None))
+            vp(val.data_ptr() if val is not None else None), vp(scratch.data_ptr() if sliced else None))
         assert rc == 0
         torch.cuda.synchronize()
 
@@ -418,6 +422,7 @@ def test_mfma_dense_heads_match_the_fp32_dense_layers(n_boards):
     assert (val[:n_boards] - ref_v).abs().max().item() <= 1e-6
     assert (pol[:n_boards].sum(1) - 1).abs().max().item() <= 1e-5
     assert (pol[n_boards:] == -7.0).all() and (val[n_boards:] == -7.0).all()
+    assert (scratch[n_boards:] == -7.0).all() and bool((scratch[:n_boards] != -7.0).all()) == sliced
     pol2 = torch.zeros_like(pol)
     run(pol2, None)                                                             # S1 evaluations: no value head
     assert torch.equal(pol2[:n_boards], pol[:n_boards])
@@ -467,8 +472,9 @@ def test_fused_trunk_from_bitplanes_is_bit_identical(filters, n_boards):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sliced", [False, True])
 @pytest.mark.parametrize("n_boards", [5, 64, 1000])
-def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards):
+def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards, sliced):
     """crl_heads_forward_legal: priors[b][j] == policy[b][labels[b][j]] bit for bit for j < counts[b]
     (0, 1, typical and the maximum 218 labels per board), nothing written past the count."""
     import ctypes
@@ -489,11 +495,13 @@ def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards)
             vp(model._val_b1.data_ptr()), vp(model._val_w2.data_ptr()))
     pol = torch.zeros((n_boards, 1968), device="cuda")
     val = torch.zeros((n_boards,), device="cuda")
-    assert _lib.lib().crl_heads_forward(*args, vp(pol.data_ptr()), vp(val.data_ptr())) == 0
+    scratch = torch.zeros((n_boards, 16), device="cuda")
+    sc = vp(scratch.data_ptr() if sliced else None)     # both calls in the same form: identical values
+    assert _lib.lib().crl_heads_forward(*args, vp(pol.data_ptr()), vp(val.data_ptr()), sc) == 0
     pri = torch.full((n_boards + 2, 256), -7.0, device="cuda")
     val2 = torch.full((n_boards + 2,), -7.0, device="cuda")
     assert _lib.lib().crl_heads_forward_legal(*args, vp(lab_d.data_ptr()), vp(cnt_d.data_ptr()),
-                                              vp(pri.data_ptr()), vp(val2.data_ptr())) == 0
+                                              vp(pri.data_ptr()), vp(val2.data_ptr()), sc) == 0
     torch.cuda.synchronize()
     pol, pri = pol.cpu().numpy(), pri.cpu().numpy()
     for b in range(n_boards):

@@ -1,15 +1,17 @@
-"""Turn the raw rocprofv3 output of tools/profile_pass.sh (gpurun_out/prof_r02/) into the tracked
-evidence: profiles/r02/*.csv (kernel stats as rocprofv3 wrote them), profiles/r02/pmc_summary.json
-and the PMC table bench.py reads (profiles/pmc_traffic.json).  python tools/distill_profiles.py"""
+"""Turn the raw rocprofv3 output of tools/profile_pass.sh (gpurun_out/prof_<round>/) into the tracked
+evidence: profiles/<round>/*.csv (kernel stats as rocprofv3 wrote them), profiles/<round>/pmc_summary.json
+and the PMC table bench.py reads (profiles/pmc_traffic.json).  python tools/distill_profiles.py [r03]"""
 import collections
 import csv
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
-DST = os.path.join(ROOT, "profiles", "r02")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
+DST = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(DST, exist_ok=True)
 
 
@@ -23,18 +25,19 @@ def per_kernel(path, last=None):
 
 passes, summary = [], {}
 shapes = {"trunk128": "4096 boards, 10 blocks x 128 filters", "trunk256": "4096 boards, 20 blocks x 256 filters",
-          "trunk64": "512 boards, 6 blocks x 64 filters"}
+          "trunk64": "512 boards, 6 blocks x 64 filters", "trunk128x3": "4096 boards, 10 blocks x 128 filters"}
 for tag, shape in shapes.items():
+    if not os.path.exists(os.path.join(SRC, tag + "_FETCH_SIZE.csv")):
+        continue
     f = per_kernel(os.path.join(SRC, tag + "_FETCH_SIZE.csv"))
     w = per_kernel(os.path.join(SRC, tag + "_WRITE_SIZE.csv"))
     for k in f:
         if "k_trunk" not in k:
             continue
-        short = k.split("::")[-1]
-        short = ",".join(short.split(",")[:3]) + ">"          # <filters, boards per workgroup, bit planes>: drop ALT, PAIR
+        short = k.split("::")[-1]                             # the name crl_trunk_kernel_name reports
         passes.append({"kernel": short, "shape": shape, "fetch_size_kb": round(f[k][0], 1),
                        "write_size_kb": round(w[k][0], 1),
-                       "source": "profiles/r02/pmc_summary.json (rocprofv3 --pmc, tools/trunk_once.py, %d launches)" % f[k][1]})
+                       "source": "profiles/%s/pmc_summary.json (rocprofv3 --pmc, tools/trunk_once.py, %d launches)" % (ROUND, f[k][1])})
         summary[short + " @ " + shape] = {"FETCH_SIZE_KB": f[k][0], "WRITE_SIZE_KB": w[k][0]}
 for tag, fmt in (("tree", "legal priors"), ("treefull", "full policies")):
     if not os.path.exists(os.path.join(SRC, tag + "_FETCH_SIZE.csv")):
@@ -49,13 +52,13 @@ for tag, fmt in (("tree", "legal priors"), ("treefull", "full policies")):
     passes.append({"kernel": "k_select_expand + k_reply", "shape": "4096 games, bit planes, %s" % fmt,
                    "fetch_size_kb": round(sum(v["FETCH_SIZE_KB"] for v in tree.values()), 1),
                    "write_size_kb": round(sum(v["WRITE_SIZE_KB"] for v in tree.values()), 1),
-                   "source": "profiles/r02/pmc_summary.json (tools/tree_once.py 4096 400 1, %s, last 50 launches; %s)"
-                             % (fmt, json.dumps(tree_shape))})
+                   "source": "profiles/%s/pmc_summary.json (tools/tree_once.py 4096 400 1, %s, last 50 launches; %s)"
+                             % (ROUND, fmt, json.dumps(tree_shape))})
 json.dump(summary, open(os.path.join(DST, "pmc_summary.json"), "w"), indent=1)
 table = {"what": "HBM-side traffic per launch from rocprofv3 PMC passes (one counter per pass; FETCH_SIZE and "
                  "WRITE_SIZE in KB as rocprofv3 reports them; bench.py applies the gfx950 x2 wide-read correction to "
-                 "FETCH_SIZE). Keyed by the kernel name rocprofv3 prints (without the trailing diagnostic template "
-                 "argument) and the launch shape; bench.py emits traffic only for an exact match.",
+                 "FETCH_SIZE). Keyed by the kernel name rocprofv3 prints (= what crl_trunk_kernel_name reports) and "
+                 "the launch shape; bench.py emits traffic only for an exact match.",
          "passes": passes}
 json.dump(table, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for n in ("c3", "c5", "c2"):

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Round-2 profile passes on the GPU box (run through gpurun).  Writes raw rocprofv3 output under
-# gpurun_out/prof_r02/ and the distilled per-kernel numbers to gpurun_out/prof_r02/summary.json.
+# The round's profile passes on the GPU box (run through gpurun): ROUND=r03 bash tools/profile_pass.sh.
+# Writes raw rocprofv3 output under gpurun_out/prof_$ROUND/; tools/distill_profiles.py turns it into
+# profiles/$ROUND/ and profiles/pmc_traffic.json.  PMC passes carry --kernel-trace only (no other trace
+# domain); the program after -- is python3 itself.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02
+ROUND=${ROUND:-r03}
+O=$R/gpurun_out/prof_$ROUND
 mkdir -p $O
 pmc() {   # name counter cmd...
   local name=$1 ctr=$2; shift 2
@@ -17,6 +20,8 @@ pmc trunk256 FETCH_SIZE python3 $R/tools/trunk_once.py 20 256 4096
 pmc trunk256 WRITE_SIZE python3 $R/tools/trunk_once.py 20 256 4096
 pmc trunk64 FETCH_SIZE python3 $R/tools/trunk_once.py 6 64 512
 pmc trunk64 WRITE_SIZE python3 $R/tools/trunk_once.py 6 64 512
+pmc trunk128x3 FETCH_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
+pmc trunk128x3 WRITE_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
 pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 1
 pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
 pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0

@@ -1,7 +1,8 @@
 // Scratch (GPU), round 3: the two bounded experiments on the production trunk kernels
 // (k_trunk_x16 with pair publishing) at 10 x 128 and 20 x 256, 4096 boards:
 //   ALT 7  staging only: weight DMA + barriers + epilogues, no fragment reads, no MFMAs (timing only)
-//   ALT 8  weight-fragment reads of the next sub-step interleaved with the MFMAs of half 1 (bit-identical)
+//   ALT 8  round 2's schedule: weight-fragment reads of the next sub-step in one clump before the MFMAs of half 1;
+//          production (ALT 0) now issues them one by one between those MFMAs (bit-identical)
 // and the time of the split-precision (f16x3) kernels on a random weight image.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I chessrl_amd/csrc tools/ubench/trunk_r3.hip -o tools/ubench/trunk_r3
 //   ./trunk_r3 [boards=4096] [reps=20]
@@ -85,7 +86,7 @@ int main(int argc, char **argv)
         printf("== 10 x 128, %d boards (pass %d)\n", boards, rep);
         const int lds = Geo16<128, 4>::lds_bytes(5);
         run("x16<128,4> pair (production)", k_trunk_x16<128, 4, 1, 0, 1>, lds, 4, 128, 10, boards, reps, b, ref, nullptr);
-        run("x16<128,4> pair, ALT 8 interleaved w reads", k_trunk_x16<128, 4, 1, 8, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
+        run("x16<128,4> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<128, 4, 1, 8, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair (production) again", k_trunk_x16<128, 4, 1, 0, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair, ALT 7 staging only", k_trunk_x16<128, 4, 1, 7, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
     }
@@ -94,7 +95,7 @@ int main(int argc, char **argv)
         printf("== 20 x 256, %d boards\n", boards);
         const int lds = Geo16<256, 2>::lds_bytes(5);
         run("x16<256,2> pair (production)", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, ref, nullptr);
-        run("x16<256,2> pair, ALT 8 interleaved w reads", k_trunk_x16<256, 2, 1, 8, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
+        run("x16<256,2> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<256, 2, 1, 8, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair (production) again", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair, ALT 7 staging only", k_trunk_x16<256, 2, 1, 7, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
     }
