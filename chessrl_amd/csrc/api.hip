@@ -678,7 +678,7 @@ int crl_trunk_forward_bitplanes(void *hip_stream, int filters, const void *dev_b
 // Batches of at most g_sliced_max boards run the heads as label slices x board blocks + a normalising
 // pass (csrc/heads.hpp: k_heads_sliced, k_policy_normalise) when the caller hands over the scratch for
 // the slice statistics; larger ones the one-pass kernels (every CU already has a workgroup there).
-static std::atomic<int> g_sliced_max{1024};
+static std::atomic<int> g_sliced_max{2048};
 
 int crl_heads_set_sliced_max(int boards)
 {

@@ -244,14 +244,14 @@ class ChessModel(object):
         if same:
             self.net.load_keras_dict(weights)
         else:
+            if getattr(self, "net", None) is not None:
+                self.graph_epoch += 1                          # another architecture: captured graphs are stale
             net = Tower(blocks, filters)
             net.load_keras_dict(weights)
             self.net = net.cast_for_inference(self.device, self._torch_dtype(filters, blocks))
             self.blocks, self.filters = blocks, filters
             self._wtiles = None
-            self.graph_epoch += 1
-        # the hand-written fused MFMA trunk (csrc/tower_pipe.hpp, tower_gen.hpp) covers 64, 128 and
-        # 256 filters in fp16
+        # the hand-written fused MFMA trunk (csrc/tower_x16.hpp) covers 64, 128 and 256 filters in fp16
         self.fused = self._will_fuse(filters, blocks)
         if self.fused:
             self._pack_fused(weights)

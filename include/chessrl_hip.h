@@ -260,7 +260,7 @@ int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int
                              void *dev_scratch_f32);
 
 /* dev_scratch_f32 of the two calls above: float [n_boards][16] or NULL.  With it, batches of at most
- * crl_heads_set_sliced_max boards (default 1024) run as label slices x board blocks (8 slices of 256
+ * crl_heads_set_sliced_max boards (default 2048: measured 16 vs 17 us there, 9 vs 17 us at 512) run as label slices x board blocks (8 slices of 256
  * labels, the value head as a ninth "slice": 9 x n_boards/16 workgroups instead of n_boards/16)
  * followed by a normalising pass that reads the slice statistics left in the scratch -- a batch of
  * 512 boards otherwise pulls the whole 1-MiB policy kernel through each of 32 CUs.  Same results for

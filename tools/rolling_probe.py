@@ -1,0 +1,64 @@
+"""Scratch (GPU): self-play games per hour over whole games, stop-and-train rounds against rolling rounds
+(SelfPlayRunner.run_rolling) at C3: G games in lockstep, S sims/move, 10x128 random-init tower.
+python tools/rolling_probe.py [G=4096] [S=800] [rounds=3] [round_size=G]
+Reports when each round was handed over and, from the timeline of finished games, the rate over every
+window of `round_size` consecutively finished games (the accounting window)."""
+import json
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from chessrl_amd.model import ChessModel
+from chessrl_amd.selfplay import SelfPlayRunner
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 800
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+N = int(sys.argv[4]) if len(sys.argv) > 4 else G
+model = ChessModel(blocks=10, filters=128, precision="f16")
+run = SelfPlayRunner(model, G, S, seed=0, noise=True, total_games=R * N, round_size=N, max_plies=4096)
+t0 = time.time()
+timeline = []                                   # (seconds, games finished so far, slots in the batch)
+taken = [0]
+orig = run.play_move
+
+
+def play_move():
+    out = orig()
+    timeline.append((time.time() - t0, taken[0] + len(run.finished), run.G))
+    return out
+
+
+run.play_move = play_move
+rounds = []
+
+
+def on_round(r, recs):
+    taken[0] += len(recs)
+    pl = np.array([len(x) for x in recs])
+    rounds.append({"round": r, "handed_over_at_s": time.time() - t0, "games": len(recs),
+                   "plies_mean": float(pl.mean()), "plies_max": int(pl.max())})
+    print(json.dumps(rounds[-1]), flush=True)
+
+
+done = run.run_rolling(R, on_round=on_round)
+total = time.time() - t0
+tl = np.array(timeline)
+# the rate over every window of N consecutively finished games: first time the count reaches k and k + N
+windows = []
+for k in range(0, int(tl[-1, 1]) - N + 1, max(1, N // 4)):
+    ta = tl[np.searchsorted(tl[:, 1], k, side="left"), 0] if k > 0 else 0.0
+    tb = tl[np.searchsorted(tl[:, 1], k + N, side="left"), 0]
+    windows.append({"from_game": k, "seconds": float(tb - ta), "games_per_hour": N / (tb - ta) * 3600.0})
+out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 f16", "round_size": N, "rounds": rounds,
+       "rounds_done": done, "seconds_total": total, "games_total": int(tl[-1, 1]), "sims_run": run.sims_run,
+       "sims_per_s_overall": run.sims_run / total, "games_per_hour_overall": tl[-1, 1] / total * 3600.0,
+       "windows_of_round_size_finished_games": windows,
+       "best_window_games_per_hour": max(w["games_per_hour"] for w in windows),
+       "note": "overall includes the start-up (every game young) and the last round's thinning tail; windows "
+               "that lie inside the refilled phase show the sustained rate"}
+print(json.dumps(out))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/rolling_probe.json", "w"), indent=1)
