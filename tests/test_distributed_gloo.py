@@ -96,3 +96,106 @@ def test_gather_records_with_an_empty_rank_and_an_empty_game():
         p.join(60)
         assert p.exitcode == 0
     assert got[0] == got[1] == [(1, 5, 0), (3, 0, None)]
+
+
+def _rolling_worker(rank, world, port, q):
+    """SelfPlayRunner.run_rolling's control flow on a runner without a GPU: ``play_move`` is a script
+    of which game ids finish at which move; everything else (round shares, take_round, the
+    all_reduce(MIN) agreement, idling of a rank whose batch ran dry) is the product's code."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import SelfPlayRunner
+    N, R = 8, 3                                                    # rounds of 8 global ids, 3 rounds
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
+    run._round_done, run.finished = {}, []
+    mine = [g for g in range(N * R) if g % world == rank]
+    # rank 0 finishes one game per move, rank 1 one game every third move: their shares of a round
+    # complete at different moves, and rank 0's batch runs dry long before rank 1's
+    finish_at = {g: (k + 1) * (1 if rank == 0 else 3) for k, g in enumerate(mine)}
+    state = {"move": 0}
+    run.active = lambda: np.array([state["move"] < max(finish_at.values())])
+
+    def play_move():
+        state["move"] += 1
+        for g, m in finish_at.items():
+            if m == state["move"]:
+                run.finished.append(records.GameRecord(g, [1, 2, 3], 0, True))
+                run._round_done[g // N] = run._round_done.get(g // N, 0) + 1
+
+    run.play_move = play_move
+    log = []
+
+    def on_round(r, recs):
+        t = dist.get_rank()
+        gathered = records.gather_records(recs, max_plies=8)       # a collective inside the callback
+        log.append((r, sorted(x.game_id for x in recs), [x.game_id for x in gathered]))
+
+    done = run.run_rolling(R, on_round=on_round, sync_every=4)
+    q.put((rank, done, log, run.finished))
+    dist.destroy_process_group()
+
+
+def test_rolling_rounds_agree_across_two_ranks():
+    """Both ranks hand every round over in order, each with ITS share of the round's ids, inside the
+    same on_round call (the record gather in it sees all 8 ids), and the loop ends on both although
+    one rank's batch ran dry 36 moves before the other's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_rolling_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: (done, log, left) for r, done, log, left in (q.get(timeout=120) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        done, log, left = got[rank]
+        assert done == 3 and left == []
+        assert [r for r, _, _ in log] == [0, 1, 2]
+        for r, own, everyone in log:
+            assert own == [g for g in range(8 * r, 8 * r + 8) if g % 2 == rank]
+            assert everyone == list(range(8 * r, 8 * r + 8))
+
+
+def test_host_helpers_of_round_3():
+    """resolve_numpy_promotion follows the installed numpy; the launcher counts GPUs without HIP;
+    noise rows drawn ahead give the choice the boundary draw gives."""
+    import bench
+    from chessrl_amd.engine import choose_children, dirichlet_row, resolve_numpy_promotion
+    probe = "legacy" if (10 * np.float32(0.1)).dtype == np.float64 else "nep50"
+    assert resolve_numpy_promotion("auto") == probe == ("nep50" if int(np.__version__.split(".")[0]) >= 2 else "legacy")
+    assert resolve_numpy_promotion("legacy") == "legacy" and resolve_numpy_promotion("nep50") == "nep50"
+    try:
+        resolve_numpy_promotion("float128")
+        raise AssertionError("accepted a bad mode")
+    except ValueError:
+        pass
+    n = bench.visible_gpus()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    os.environ["HIP_VISIBLE_DEVICES"] = "0"
+    try:
+        m = bench.visible_gpus()
+        assert m is None or m <= 1
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
+    rng = np.random.default_rng(3)
+    G = 6
+    nchild = np.array([3, 0, 7, 1, 218, 20])
+    visits = rng.integers(1, 50, (G, 256))
+    root = np.array([int(visits[g, :nchild[g]].sum()) + 1 for g in range(G)])
+    plies = np.array([0, 10, 29, 30, 77, 200])
+    mk = lambda: [np.random.default_rng([5, g]) for g in range(G)]
+    at_boundary = choose_children(visits, nchild, root, plies, noise=True, rngs=mk())
+    ahead = [dirichlet_row(r, int(k)) if k else None for r, k in zip(mk(), nchild)]
+    assert np.array_equal(choose_children(visits, nchild, root, plies, noise=True, rngs=None, noise_rows=ahead),
+                          at_boundary)
+    ahead[2] = ahead[2][:-1]                                        # a row of the wrong length is refused
+    try:
+        choose_children(visits, nchild, root, plies, noise=True, noise_rows=ahead)
+        raise AssertionError("accepted a noise row of the wrong length")
+    except RuntimeError:
+        pass

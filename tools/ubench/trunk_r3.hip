@@ -89,6 +89,8 @@ int main(int argc, char **argv)
         run("x16<128,4> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<128, 4, 1, 8, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair (production) again", k_trunk_x16<128, 4, 1, 0, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair, ALT 7 staging only", k_trunk_x16<128, 4, 1, 7, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
+        run("x16<128,4> pair, ALT 9 L2 prefetch +8", k_trunk_x16<128, 4, 1, 9, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
+        run("x16<128,4> pair, ALT 10 L2 prefetch +16", k_trunk_x16<128, 4, 1, 10, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
     }
     {
         Bufs b = make(256, 20, boards, 1);
@@ -98,6 +100,9 @@ int main(int argc, char **argv)
         run("x16<256,2> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<256, 2, 1, 8, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair (production) again", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair, ALT 7 staging only", k_trunk_x16<256, 2, 1, 7, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
+        run("x16<256,2> pair, ALT 9 L2 prefetch +8", k_trunk_x16<256, 2, 1, 9, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
+        run("x16<256,2> pair, ALT 10 L2 prefetch +16", k_trunk_x16<256, 2, 1, 10, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
+        run("x16<256,2> pair (production) once more", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
     }
     {   // split precision: three MFMAs per product over a 3x weight image (random values: time only)
         Bufs b = make(128, 10, boards, 3);
