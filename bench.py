@@ -56,7 +56,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
 PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-GAME_LENGTH_C3 = 160.04     # moves per game, 4096 complete games: profiles/r02/finite_run_c3_4096_games.json
+GAME_LENGTH_C3 = 160.04     # moves per game, 4096 complete games: profiles/r02/finite_run_c3_4096_games.json; profiles/r03/rolling_probe.json: 320.1 / 318.7 / 320.2 plies over three rounds
 
 
 def parse():
@@ -560,7 +560,7 @@ def main():
             "move_boundary": boundary, "value_incl_boundaries": incl,
             "moves_per_sec": (incl or total_sims / max_dt) / a.sims,
             # games/hour: a random-init 10x128 net at 800 sims/move plays 160.04 moves (320 plies) per
-            # game on average (4096 complete games, profiles/r02/finite_run_c3_4096_games.json);
+            # game on average (4096 complete games, profiles/r02/finite_run_c3_4096_games.json; profiles/r03/rolling_probe.json: 320.1 / 318.7 / 320.2 plies over three rounds);
             # steady state with refill = moves/s / moves per game.  Only stated for that config.
             "self_play_games_per_hour_est": ((incl or total_sims / max_dt) / a.sims / GAME_LENGTH_C3 * 3600.0
                                              if (a.sims, B, F) == (800, 10, 128) else None),

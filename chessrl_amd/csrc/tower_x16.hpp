@@ -38,7 +38,6 @@ template <int F, int NB_, int SPLIT_ = 0>
 struct Geo16 {
     static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
     static constexpr int SPLIT = SPLIT_;
-    static constexpr int F_ = F;
     static constexpr int LO_OFF = F * 2;                // byte offset of the lo half inside an activation row
     static constexpr int NB = NB_;                      // boards per workgroup
     static constexpr int WPB = 8 / NB;                  // waves per board
@@ -148,28 +147,6 @@ __device__ inline void stage_bias_x16(const float *bias, lds_byte *lds, int conv
         (__attribute__((address_space(3))) void *)(lds + G::BIAS_OFF + (conv & 1) * F * 4 + wave_u * 256), 4, 0, 0);
 }
 
-// Warm the XCD's L2 for the two weight tiles t .. t+1 + PF tiles ahead.  The weight set (6 / 48 MB)
-// does not fit the 4-MiB L2 of an XCD: every round of workgroups streams it in again from the
-// Infinity Cache, and the ~32 workgroups of an XCD march through it in step, so the first to ask for
-// a line waits for the fabric and the others wait with it.  Here each workgroup touches 1/32 of the
-// lines of a tile pair well ahead of its use -- one 4-byte LDS-DMA per line into a scratch word (no
-// register, counted by the same vmcnt waits as the tiles) -- so that the tile DMAs find L2 hits.
-template <class G, int PF>
-__device__ inline void l2_prefetch_pair(const unsigned char *wts, lds_byte *lds, int t, int n_tiles, int lane, int wave_u)
-{
-    constexpr int LINES = 2 * G::TILE_BYTES / 128;      // 128-byte lines of a tile pair
-    constexpr int PER_WG = LINES / 32;                  // this workgroup's share
-    static_assert(PER_WG >= 1 && PER_WG <= 64 && G::WRING_OFF - (G::BIAS_OFF + 2 * G::F_ * 4) >= 256, "scratch behind the bias rows");
-    if (wave_u != 7 || t + PF + 1 >= n_tiles) return;
-    const int wgx = (blockIdx.x >> 3) & 31;             // index among the workgroups sharing an XCD (round-robin dispatch)
-    if (lane < PER_WG) {
-        const unsigned char *src = wts + (size_t)(t + PF) * G::TILE_BYTES + (size_t)(wgx * PER_WG + lane) * 128;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)src,
-            (__attribute__((address_space(3))) void *)(lds + G::BIAS_OFF + 2 * G::F_ * 4), 4, 0, 0);
-    }
-}
-
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vmcnt_n()
@@ -226,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     static_assert(ALT == 0, "diagnostic variants are for tools/ubench/trunk_variants.hip only");
 #endif
     typedef Geo16<F, NB, SPLIT> G;
-    constexpr int L2PF = (ALT == 9 || ALT == 10) ? (ALT == 9 ? 8 : 16) : 0;      // harness: L2 prefetch distance in tiles
     static_assert(!SPLIT || (!GROUP && (ALT == 0 || ALT == 2)), "split precision runs the plain / pair pipelines");
     constexpr int PT = G::PT, CT = G::CT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
@@ -244,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
-    static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2 || ALT >= 7)), "pair publishing: even tile counts per layer");
+    static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2 || ALT == 7 || ALT == 8)), "pair publishing: even tile counts per layer");
     static_assert(!SPLIT || ALT != 8, "the split-precision kernels run the production schedule");
     constexpr int GK = 3;                               // GROUP: taps (= tiles) per barrier
     constexpr int GRG = NB == 2 ? 4 : 3;                // GROUP: groups in the weight ring
@@ -414,7 +390,6 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                         const int slot_cur = slot_add(slot_tap, i / G::SPT);
                         if (t + 3 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 3, tid, wave_u, slot_add(slot_cur, 3));
                         if (t + 4 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 4, tid, wave_u, slot_add(slot_cur, 4));
-                        if constexpr (L2PF > 0) l2_prefetch_pair<G, L2PF>(wts, lds, t + 3, n_tiles, lane, wave_u);
                     }
                 } else if constexpr (s == G::SPT - 1) {
                     // publish tile t+1 before the half that prefetches its first fragments;

@@ -4,6 +4,9 @@
 //   ALT 8  round 2's schedule: weight-fragment reads of the next sub-step in one clump before the MFMAs of half 1;
 //          production (ALT 0) now issues them one by one between those MFMAs (bit-identical)
 // and the time of the split-precision (f16x3) kernels on a random weight image.
+// (A third variant was measured with this harness and removed again: warming each XCD's L2 for the weight
+// tiles 8 / 16 tiles ahead, 1/32 of the lines per workgroup through 4-byte LDS-DMAs: +1.0 ... +1.5 % SLOWER
+// at both sizes -- profiles/r03/trunk_r3_l2_prefetch.log.  The L2 -> LDS stream is not waiting for the fabric.)
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I chessrl_amd/csrc tools/ubench/trunk_r3.hip -o tools/ubench/trunk_r3
 //   ./trunk_r3 [boards=4096] [reps=20]
 #define CRL_HARNESS 1
@@ -89,8 +92,6 @@ int main(int argc, char **argv)
         run("x16<128,4> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<128, 4, 1, 8, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair (production) again", k_trunk_x16<128, 4, 1, 0, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
         run("x16<128,4> pair, ALT 7 staging only", k_trunk_x16<128, 4, 1, 7, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
-        run("x16<128,4> pair, ALT 9 L2 prefetch +8", k_trunk_x16<128, 4, 1, 9, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
-        run("x16<128,4> pair, ALT 10 L2 prefetch +16", k_trunk_x16<128, 4, 1, 10, 1>, lds, 4, 128, 10, boards, reps, b, out, &ref);
     }
     {
         Bufs b = make(256, 20, boards, 1);
@@ -100,9 +101,6 @@ int main(int argc, char **argv)
         run("x16<256,2> pair, ALT 8 clumped w reads (r2)", k_trunk_x16<256, 2, 1, 8, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair (production) again", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair, ALT 7 staging only", k_trunk_x16<256, 2, 1, 7, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
-        run("x16<256,2> pair, ALT 9 L2 prefetch +8", k_trunk_x16<256, 2, 1, 9, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
-        run("x16<256,2> pair, ALT 10 L2 prefetch +16", k_trunk_x16<256, 2, 1, 10, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
-        run("x16<256,2> pair (production) once more", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
     }
     {   // split precision: three MFMAs per product over a 3x weight image (random values: time only)
         Bufs b = make(128, 10, boards, 3);
