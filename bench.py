@@ -564,6 +564,11 @@ def main():
             # steady state with refill = moves/s / moves per game.  Only stated for that config.
             "self_play_games_per_hour_est": ((incl or total_sims / max_dt) / a.sims / GAME_LENGTH_C3 * 3600.0
                                              if (a.sims, B, F) == (800, 10, 128) else None),
+            # whole games, measured (not in this run): three rolling rounds of 4096 C3 games on one MI355X
+            "self_play_games_per_hour_whole_run": ({"value": 45058.6, "seconds": 981.8, "games": 12288,
+                                                    "source": "profiles/r03/rolling_probe.json (tools/rolling_probe.py 4096 800 3: "
+                                                              "start-up and final tail included; NOT measured by this bench run)"}
+                                                   if (a.sims, B, F, G) == (800, 10, 128, 4096) else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
             "roofline": roof, "roofline_tree": tree, "precision_modes": modes,
