@@ -608,6 +608,13 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, v == 0, v == nv - 1);
             else run_tap(std::integral_constant<int, 4>{}, v == 0, v == nv - 1);
             if constexpr (PAIR) slot_tap = slot_add(slot_tap, 4 / G::SPT);
+            // The fragments prefetched for the next tap are in flight across this loop's back-edge, where
+            // hipcc -- which cannot see the inline-asm reads -- is free to COPY their registers (phi moves)
+            // before the data has landed.  It does so in the 64-filter split kernels (found as run-to-run
+            // differences once a second process delayed the LDS returns); there the reads are drained
+            // here.  tools/check_asm_hazards.py walks the ISA of every trunk kernel for such reads and is
+            // run by tests/test_host_and_cabi.py on every build.
+            if constexpr (SPLIT && F == 64) wait_lgkm<0>();
         }
         }
 

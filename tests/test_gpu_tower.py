@@ -118,3 +118,37 @@ def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
     rc = eng.root_children()
     assert (rc["root_visits"] == 9).all()
     eng.close()
+
+
+def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu():
+    """Launch-to-launch identity of every trunk kernel family (64 / 128 / 256 filters, both
+    precision modes, both workgroup geometries) while a second process hammers the GPU with small
+    kernels and context churn: its workgroups share our CUs, LDS latencies jitter, and a kernel that
+    reads a register before its hand-counted ``s_waitcnt`` has made it valid shows different bits
+    (what tools/check_asm_hazards.py looks for statically; this is the dynamic half)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from chessrl_amd import model as M
+    from chessrl_amd.model import ChessModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    disturber = subprocess.Popen([sys.executable, os.path.join(root, "tools", "trunk_stability_probe.py"),
+                                  "disturb", "100000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        for blocks, filters, n in ((1, 64, 256), (1, 64, 2048), (2, 128, 256), (2, 128, 2048), (1, 256, 256), (1, 256, 1024)):
+            m = ChessModel(blocks=blocks, filters=filters, seed=5, precision="f16")
+            planes = M._probe_bitplanes(m.device, 256).repeat(n // 256, 1).contiguous()
+            m.precision_requested = "auto"
+            m._pack_fused(m.weights)
+            for mode in ("f16", "f16x3"):
+                seen = set()
+                for _ in range(60):
+                    _, hp = m._run_fused(planes, precision=mode)
+                    torch.cuda.synchronize()
+                    seen.add(hashlib.md5(hp.cpu().numpy().tobytes()).hexdigest())
+                assert disturber.poll() is None, "the disturber ended early"
+                assert len(seen) == 1, (blocks, filters, n, mode, len(seen))
+    finally:
+        disturber.kill()
+        disturber.wait()

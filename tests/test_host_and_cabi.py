@@ -300,3 +300,29 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
             assert planes[tap, part, g, r, c ^ ((-(r >> 2)) & 3), e] == want, (conv, tap, part, g, r, c, e)
         assert np.abs(hi + lo - k).max() <= 2.0 ** -20 * np.abs(k).max()
         off += len(parts) * 9 * cin * F_
+
+
+def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(tmp_path):
+    """The trunk kernels issue their fragment reads as inline-asm ``ds_read_b128`` with hand-counted
+    ``s_waitcnt lgkmcnt`` (hipcc would otherwise undo the software pipeline), so hipcc does not know
+    that those registers are not valid yet and may copy them -- phi moves at a loop back-edge -- before
+    the data has landed: results then depend on LDS latency (found in round 3: the 64-filter
+    split-precision kernels differed from run to run once a second process shared the GPU).
+    tools/check_asm_hazards.py walks the ISA of every k_trunk_x16 kernel the library contains and
+    reports any instruction reading a register whose ds_read is still in flight."""
+    import shutil
+    import subprocess
+    import sys
+    from chessrl_amd import _lib
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    asm = str(tmp_path / "api.s")
+    flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.check_call(["hipcc"] + flags + ["-S", "--offload-device-only",
+                                               os.path.join(ROOT, "chessrl_amd", "csrc", "api.hip"), "-o", asm],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py"), asm],
+                       capture_output=True, text=True)
+    kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
+    assert len(kernels) >= 20, r.stdout                       # every dispatched (F, NB, BITS, PAIR, GROUP, SPLIT)
+    assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
