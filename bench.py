@@ -395,9 +395,18 @@ def main():
         torch.cuda.synchronize()
 
     # a window shorter than a move is centred on the middle of a move (trees pre-grown un-timed)
+    # one shortened move first (un-timed): loads every move-boundary kernel and host path once, so that a
+    # boundary timed later is a steady-state one even when it is the first full-length boundary of the process
+    run.step()
+    run.end_move()
     pre = 0
     if a.steps < a.sims:
-        pre = max(0, (a.sims - a.steps) // 2 - a.warmup)
+        # mid-move; when the window fits into the second half of the move it starts just behind the
+        # point where the runner draws the move's Dirichlet noise ahead (sims // 2), so that no host
+        # work of the runner falls into a window of a few tens of milliseconds
+        second_half = a.sims // 2 + 8
+        start = second_half if a.steps <= a.sims - second_half - 1 else (a.sims - a.steps) // 2
+        pre = max(0, start - a.warmup)
     for _ in range(pre + a.warmup):
         run.step()
     window_start = run._sims_in_move or 0
@@ -516,9 +525,9 @@ def main():
             if model.precision == "f16" and a.strict_steps > 0 and world == 1:
                 model.set_precision("f16x3")
                 run.begin_move()                                # fresh trees (the profiled move is abandoned)
-                pre = min(max(8, run.sims // 4), run.sims // 2)
-                n3 = max(1, min(a.strict_steps, run.sims - pre - 1))
-                for _ in range(pre):
+                grow = min(max(8, run.sims // 4), run.sims // 2)
+                n3 = max(1, min(a.strict_steps, run.sims - grow - 1))
+                for _ in range(grow):
                     eng.step()                                  # (re-captures the graph) to mid-move
                 torch.cuda.synchronize()
                 cs0 = eng.ctx.counters()["sims"]
@@ -527,7 +536,7 @@ def main():
                     eng.step()
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - ts
-                run._sims_in_move = pre + n3
+                run._sims_in_move = grow + n3
                 k3 = trunk_kernel_name(F, G, int(eng.bitplanes) | 2)
                 modes["f16x3"] = {"simulations_per_s": (eng.ctx.counters()["sims"] - cs0) / dts,
                                   "ms_per_step": dts / n3 * 1e3, "steps": n3,

@@ -2,7 +2,7 @@
 therefore READ (copy, at a loop back-edge or a branch join) the destination registers before the
 hand-counted ``s_waitcnt lgkmcnt`` that makes the data valid.  This walks every k_trunk_x16 kernel of a
 device assembly in file order, tracks the destinations of asm ds_reads that are still in flight
-(retired oldest-first by the lgkmcnt immediates) and reports every instruction that reads one.
+(retired oldest-first by the lgkmcnt immediates) and reports every instruction that reads or overwrites one.
 hipcc ... -S --offload-device-only csrc/api.hip -o api.s ; python tools/check_asm_hazards.py api.s"""
 import re
 import sys
@@ -47,14 +47,21 @@ def check(lines, name):
         if op.startswith("ds_read") or op.startswith("ds_write") or op.startswith("s_load"):
             # a compiler-visible LDS / SMEM op also counts in lgkmcnt: it sits in the queue like the asm reads
             pending.append((set(), n))
-        srcs = toks[1:] if not op.startswith(("ds_write", "global_store", "buffer_store")) else toks
+        stores = op.startswith(("ds_write", "global_store", "buffer_store", "global_load_lds", "s_"))
+        srcs = toks if stores else toks[1:]
         for t in srcs:
             r, kind = regs(t)
             if kind != "v":
                 continue
             for d, at in pending:
                 if r & d:
-                    bad.append((n, l, at))
+                    bad.append((n, l + "   [READS]", at))
+        if not stores and toks:                  # ... or overwrites one: the late LDS return would clobber the new value
+            r, kind = regs(toks[0])
+            if kind == "v":
+                for d, at in pending:
+                    if r & d:
+                        bad.append((n, l + "   [OVERWRITES]", at))
     return bad
 
 
