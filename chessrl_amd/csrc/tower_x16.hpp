@@ -30,10 +30,11 @@ namespace crl_tower {
 // lo = fp16(x - hi), side by side in its LDS row ([hi: F channels | lo: F channels]), the folded
 // weights likewise as two fp16 images, and a product is hi.Whi + hi.Wlo + lo.Whi (the dropped
 // lo.Wlo term is 2^-22 relative): three MFMAs for fp32-grade results -- the same device as
-// csrc/heads.hpp.  It is run as a convolution over an EXTENDED input: per spatial tap three "parts"
-// (x = hi against Whi, hi against Wlo, lo against Whi; the stem's 0/1 planes have no lo: two parts),
-// each a virtual tap like the channel halves of a 256-filter layer, so the tap loop, the weight
-// ring and the pipeline are the ones below; the weight image lists the planes in that order.
+// csrc/heads.hpp.  It is run as a convolution over an EXTENDED input: per spatial tap two weight "parts",
+// the planes of Whi and the planes of Wlo, each a virtual tap like the channel halves of a 256-filter
+// layer, so the tap loop, the weight ring and the pipeline are the ones below; Whi passes through the ring
+// ONCE and every one of its weight sub-steps feeds two MFMA sub-steps, against hi and against lo (the
+// stem's 0/1 planes have no lo: one); the weight image lists the planes in that order.
 template <int F, int NB_, int SPLIT_ = 0>
 struct Geo16 {
     static_assert(F == 64 || F == 128 || F == 256, "supported filter counts");
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int r = lane & 15, q = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int n_convs = 1 + 2 * n_blocks;
-    // SPLIT: two parts per stem tap (Whi, Wlo against the exact 0/1 planes), three per block tap
-    const int tiles_stem = 9 * (SPLIT ? 2 : 1) * (128 / G::KT), tiles_conv = 9 * (SPLIT ? 3 : 1) * (F / G::KT);
+    // SPLIT: two weight parts per tap (the planes of Whi, then of Wlo)
+    const int tiles_stem = 9 * (SPLIT ? 2 : 1) * (128 / G::KT), tiles_conv = 9 * (SPLIT ? 2 : 1) * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
 
@@ -322,28 +323,36 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 
         // one (virtual) tap = NS sub-steps of 32 input channels; sub-step i reads channel block i of
         // the tap's activation rows and sub-step i % SPT of weight tile t_tap0 + i / SPT
-        auto run_tap = [&](auto NSC, bool first_tap, bool last_tap) {
-            constexpr int NS = decltype(NSC)::value;
+        // DUP = 2 (split precision, the Whi planes of a residual conv): every weight sub-step is used by
+        // TWO MFMA sub-steps, first against the hi half of the activation rows, then against the lo
+        // half LO_OFF bytes further -- the products hi.Whi and lo.Whi share one pass of Whi through the
+        // ring and one set of weight fragment reads.  NS counts MFMA sub-steps, NS / DUP weight sub-steps.
+        auto run_tap = [&](auto NSC, auto DUPC, bool first_tap, bool last_tap) {
+            constexpr int NS = decltype(NSC)::value, DUP = decltype(DUPC)::value;
+            static_assert(DUP == 1 || (SPLIT && DUP == 2 && ALT != 8), "shared weight sub-steps belong to the split kernels");
             const int t_tap0 = t;
             auto fetch_xa = [&](auto IC, bool next_tap) {
                 constexpr int i = decltype(IC)::value;
                 if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }       // timing only: no fragment reads
 #pragma unroll
-                for (int pt = 0; pt < HP; pt++) xa[pt] = lds_read16_asm<i * 64>(ab[next_tap ? 1 : 0][pt]);
+                for (int pt = 0; pt < HP; pt++)
+                    xa[pt] = lds_read16_asm<(i / DUP) * 64 + (i % DUP) * G::LO_OFF>(ab[next_tap ? 1 : 0][pt]);
             };
             auto fetch_xb = [&](auto IC) {
                 constexpr int i = decltype(IC)::value;
                 if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }
 #pragma unroll
-                for (int pt = 0; pt < HP; pt++) xb[pt] = lds_read16_asm<i * 64>(ab[0][HP + pt]);
+                for (int pt = 0; pt < HP; pt++)
+                    xb[pt] = lds_read16_asm<(i / DUP) * 64 + (i % DUP) * G::LO_OFF>(ab[0][HP + pt]);
             };
             // Ring of four: a tap's tiles sit in consecutive slots (a tap is 1, 2 or 4 tiles and
             // starts on a multiple of that), so slot and sub-step are immediates on top of the tap's
             // first slot.  Ring of five (PAIR): one base register per tile of the tap (slots wrap).
-            constexpr int TPT = NS / G::SPT;
-            static_assert((TPT == 1 || TPT == 2 || TPT == 4) && PIPE_RING == 4, "ring");
+            constexpr int NSW = NS / DUP;                // weight sub-steps of the tap
+            constexpr int TPT = NSW / G::SPT;
+            static_assert((TPT == 1 || TPT == 2 || TPT == 4) && PIPE_RING == 4 && NSW % 2 == 0, "ring");
             int wv[PAIR ? TPT : 1], wv_nxt;
             if constexpr (PAIR) {
 #pragma unroll
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 wv[0] = w0 + (t_tap0 & (PIPE_RING - 1)) * G::TILE_BYTES;
                 wv_nxt = w0 + ((t_tap0 + TPT) & (PIPE_RING - 1)) * G::TILE_BYTES;
             }
-            auto fetch_w1 = [&](auto IC, auto CC, bool next_tap, half8 (&dst)[CT]) {
+            auto fetch_w1 = [&](auto IC, auto CC, bool next_tap, half8 (&dst)[CT]) {     // IC: weight sub-step
                 constexpr int i = decltype(IC)::value, ct = decltype(CC)::value;
                 if constexpr (ALT == 7) return;
                 if constexpr (ALT == 6) { if (t > 1) return; }
@@ -369,10 +378,14 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
             }
             static_for<0, NS>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
-                constexpr int s = i % G::SPT;
-                constexpr int cur = i % 2, nxt = 1 - cur;
-                if constexpr (PAIR) {
-                    if constexpr (s == G::SPT - 1 && ((i / G::SPT) & 1) == 1) {
+                constexpr int wi = i / DUP;              // weight sub-step of this MFMA sub-step
+                constexpr bool w_first = i % DUP == 0, w_last = i % DUP == DUP - 1;
+                constexpr int s = wi % G::SPT;
+                constexpr int cur = wi % 2, nxt = 1 - cur;
+                if constexpr (!w_first) {
+                    // second use of this weight sub-step: no tile event
+                } else if constexpr (PAIR) {
+                    if constexpr (s == G::SPT - 1 && ((wi / G::SPT) & 1) == 1) {
                         // start of the last sub-step of an odd tile t: tiles t+1, t+2 (moved at the
                         // previous sync, the only transfers in flight) are published; tiles <= t-1
                         // are dead and their slots take tiles t+3, t+4
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                             bias_staged = true;
                             if (conv + 1 < n_convs) stage_bias_x16<G, F>(bias, lds, conv + 1, lane, wave_u);
                         }
-                        const int slot_cur = slot_add(slot_tap, i / G::SPT);
+                        const int slot_cur = slot_add(slot_tap, wi / G::SPT);
                         if (t + 3 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 3, tid, wave_u, slot_add(slot_cur, 3));
                         if (t + 4 < n_tiles) stage_wtile_x16<G, 0>(wts, lds, t + 4, tid, wave_u, slot_add(slot_cur, 4));
                     }
@@ -447,11 +460,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                     static_for<0, HP * CT>([&](auto KC) {
                         constexpr int k = decltype(KC)::value, pt = k / CT, ct = k % CT;
                         acc[HP + pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[cur][ct], xb[pt], acc[HP + pt][ct], 0, 0, 0);
-                        if constexpr (k < CT) {
+                        if constexpr (k < CT && w_last) {                 // the next MFMA sub-step has new weights
                             __builtin_amdgcn_sched_barrier(0);
                             if (issued) {
                                 if constexpr (wrap) fetch_w1(std::integral_constant<int, 0>{}, KC, true, w[nxt]);
-                                else fetch_w1(std::integral_constant<int, i + 1>{}, KC, false, w[nxt]);
+                                else fetch_w1(std::integral_constant<int, wi + 1>{}, KC, false, w[nxt]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                         fetch_w(std::integral_constant<int, 0>{}, true, w[nxt]);
                     } else {
                         fetch_xa(std::integral_constant<int, i + 1>{}, false);
-                        fetch_w(std::integral_constant<int, i + 1>{}, false, w[nxt]);
+                        fetch_w(std::integral_constant<int, wi + 1>{}, false, w[nxt]);
                     }
                 }
                 if (!issued) wait_lgkm<0>();
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (s == G::SPT - 1) t++;
+                if constexpr (s == G::SPT - 1 && w_last) t++;
             });
         };
 
@@ -490,8 +503,10 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         // (GROUP: virtual taps of 64 channels, so it is the stem's 128 planes that split in two)
         const int hshift = GROUP ? (conv == 0 ? 1 : 0) : ((conv != 0 && F == 256) ? 1 : 0);
         constexpr int chstep = GROUP ? 128 : 256;       // bytes between the channel halves of a spatial tap
-        // SPLIT: a spatial tap is parts x pieces virtual taps (pieces = channel halves as above)
-        const int parts = SPLIT ? (conv == 0 ? 2 : 3) : 1;
+        // SPLIT: a spatial tap is parts x pieces virtual taps (pieces = channel halves as above); part 0 =
+        // the planes of Whi, used against hi and -- in the residual convs, whose input has a lo half -- in
+        // the same pass against lo (run_tap DUP = 2); part 1 = the planes of Wlo against hi
+        const int parts = SPLIT ? 2 : 1;
         const int per_tap = parts << hshift;
         const int nv = 9 * per_tap;
         // Activation row address of block pt for virtual tap v: the lane's own row shifted by
@@ -501,10 +516,11 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         auto vtap_rows = [&](int v, int (&dst)[PT]) {
             int tap, choff;
             if constexpr (SPLIT) {
-                // order inside a spatial tap: part (hi.Whi, hi.Wlo, lo.Whi) major, channel piece minor
+                // order inside a spatial tap: part (Whi, Wlo) major, channel piece minor; the lo half of
+                // the rows is an immediate of the reads (run_tap)
                 tap = v / per_tap;
-                const int rem = v - tap * per_tap, part = rem >> hshift;
-                choff = (rem & ((1 << hshift) - 1)) * chstep + (part == 2 ? G::LO_OFF : 0);
+                const int rem = v - tap * per_tap;
+                choff = (rem & ((1 << hshift) - 1)) * chstep;
             } else {
                 tap = v >> hshift;
                 choff = (v & ((1 << hshift) - 1)) * chstep;
@@ -605,16 +621,26 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
             for (int pt = 0; pt < PT; pt++) ab[0][pt] = ab[1][pt];
             vtap_rows(v + 1 < nv ? v + 1 : 0, ab[1]);
-            if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, v == 0, v == nv - 1);
-            else run_tap(std::integral_constant<int, 4>{}, v == 0, v == nv - 1);
+            constexpr std::integral_constant<int, 1> once{};
+            if constexpr (SPLIT) {
+                constexpr std::integral_constant<int, 2> twice{};
+                const bool whi = ((v % per_tap) >> hshift) == 0;         // part 0
+                if (conv != 0 && whi) {                                  // Whi against hi and lo
+                    if (F == 64) run_tap(std::integral_constant<int, 4>{}, twice, v == 0, v == nv - 1);
+                    else run_tap(std::integral_constant<int, 8>{}, twice, v == 0, v == nv - 1);
+                } else if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, once, v == 0, v == nv - 1);
+                else run_tap(std::integral_constant<int, 4>{}, once, v == 0, v == nv - 1);
+            } else
+            if (F == 64 && conv != 0) run_tap(std::integral_constant<int, 2>{}, once, v == 0, v == nv - 1);
+            else run_tap(std::integral_constant<int, 4>{}, once, v == 0, v == nv - 1);
             if constexpr (PAIR) slot_tap = slot_add(slot_tap, 4 / G::SPT);
             // The fragments prefetched for the next tap are in flight across this loop's back-edge, where
             // hipcc -- which cannot see the inline-asm reads -- is free to COPY their registers (phi moves)
-            // before the data has landed.  It does so in the 64-filter split kernels (found as run-to-run
-            // differences once a second process delayed the LDS returns); there the reads are drained
-            // here.  tools/check_asm_hazards.py walks the ISA of every trunk kernel for such reads and is
+            // before the data has landed.  It does so in the split kernels, whose tap loop has several
+            // bodies (found in the 64-filter ones as run-to-run differences once a second process delayed
+            // the LDS returns); there the reads are drained here.  tools/check_asm_hazards.py walks the ISA of every trunk kernel for such reads and is
             // run by tests/test_host_and_cabi.py on every build.
-            if constexpr (SPLIT && F == 64) wait_lgkm<0>();
+            if constexpr (SPLIT) wait_lgkm<0>();
         }
         }
 

@@ -318,11 +318,10 @@ class ChessModel(object):
             if want_f16:
                 tiles.append(t_hi.contiguous().reshape(-1))
             if want_x3:
-                # CRL_TRUNK_SPLIT: per tap the planes of Whi, of Wlo = fp16(W - Whi), and of Whi again
-                # (products hi.Whi, hi.Wlo, lo.Whi); the stem's 0/1 planes have no lo part: Whi, Wlo
+                # CRL_TRUNK_SPLIT: per tap the planes of Whi, then of Wlo = fp16(W - Whi); the kernel
+                # uses every Whi plane for hi.Whi and lo.Whi in one pass, the Wlo planes for hi.Wlo
                 t_lo = planes_of((k - hi.float()).to(torch.float16))
-                parts = [t_hi, t_lo] if conv == "stem" else [t_hi, t_lo, t_hi]
-                tiles3.append(torch.stack(parts, dim=1).contiguous().reshape(-1))          # [tap][part][g][row]...
+                tiles3.append(torch.stack([t_hi, t_lo], dim=1).contiguous().reshape(-1))   # [tap][part][g][row]...
             biases.append(b)
         kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][F][1][1]
         kv, bv = _fold(w, "value.conv", "value.bn")            # [1][F][1][1]

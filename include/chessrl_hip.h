@@ -215,8 +215,9 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
  * accumulation), which puts the outputs within ~1e-5 of an fp32 evaluation of the same weights
  * whatever the weights are (one fp16 MFMA per product is within 1e-3 of fp32 for Keras-initialised
  * and lightly trained towers but not for sharp ones; model.py:31-63 runs fp32).  The weight image
- * then lists, per conv and spatial tap, the planes of Whi, of Wlo = fp16(W - Whi), and of Whi
- * again (the stem, whose 0/1 input has no lo part: Whi, Wlo), each in the plane order above. */
+ * then lists, per conv and spatial tap, the planes of Whi and then the planes of Wlo = fp16(W - Whi),
+ * each in the plane order above (twice the size of the plain image; a Whi plane serves hi.Whi and
+ * lo.Whi while it sits in LDS). */
 #define CRL_TRUNK_BITPLANES 1
 #define CRL_TRUNK_SPLIT 2
 int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,

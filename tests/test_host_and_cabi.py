@@ -279,10 +279,10 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
             assert planes[tap, g, r, pos, e] == want, (conv, tap, g, r, c, e)
         off += 9 * cin * F_
     assert sorted({(r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3) for r in range(F_)}) == list(range(F_))
-    # the split-precision image (CRL_TRUNK_SPLIT): per tap the planes of Whi, Wlo = fp16(W - Whi) and
-    # Whi again (stem: Whi, Wlo), each in the same plane order; hi + lo carries W to ~2^-22
+    # the split-precision image (CRL_TRUNK_SPLIT): per tap the planes of Whi, then of Wlo = fp16(W - Whi),
+    # each in the same plane order; hi + lo carries W to ~2^-22
     img3 = m._wtiles3.float().numpy()
-    assert img3.size == 2 * 9 * 128 * F_ + 2 * 3 * 9 * F_ * F_
+    assert img3.size == 2 * (9 * 128 * F_ + 2 * 9 * F_ * F_)
     off = 0
     for conv, bn in convs:
         k, _ = M._fold(w, conv, bn)
@@ -290,7 +290,7 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
         hi = k.astype(np.float16).astype(np.float32)
         lo = (k - hi).astype(np.float16).astype(np.float32)
         cin = 128 if conv == "stem" else F_
-        parts = [hi, lo] if conv == "stem" else [hi, lo, hi]
+        parts = [hi, lo]
         planes = img3[off:off + len(parts) * 9 * cin * F_].reshape(9, len(parts), cin // 32, F_, 4, 8)
         for _ in range(400):
             tap, part, g, r, c, e = (int(rng.integers(n)) for n in (9, len(parts), cin // 32, F_, 4, 8))

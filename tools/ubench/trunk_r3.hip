@@ -102,13 +102,13 @@ int main(int argc, char **argv)
         run("x16<256,2> pair (production) again", k_trunk_x16<256, 2, 1, 0, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
         run("x16<256,2> pair, ALT 7 staging only", k_trunk_x16<256, 2, 1, 7, 1>, lds, 2, 256, 20, boards, 5, b, out, &ref);
     }
-    {   // split precision: three MFMAs per product over a 3x weight image (random values: time only)
-        Bufs b = make(128, 10, boards, 3);
+    {   // split precision: three MFMAs per product over a 2x weight image (random values: time only)
+        Bufs b = make(128, 10, boards, 2);
         printf("== f16x3 (split operands), %d boards\n", boards);
         run("x16<128,2> pair split, 10 x 128", k_trunk_x16<128, 2, 1, 0, 1, 0, 1>, Geo16<128, 2, 1>::lds_bytes(5), 2, 128, 10, boards, reps, b, ref, nullptr);
-        Bufs c = make(256, 20, boards, 3);
+        Bufs c = make(256, 20, boards, 2);
         run("x16<256,1> split, 20 x 256", k_trunk_x16<256, 1, 1, 0, 0, 0, 1>, Geo16<256, 1, 1>::lds_bytes(4), 1, 256, 20, boards, 3, c, ref, nullptr);
-        Bufs d = make(64, 6, boards, 3);
+        Bufs d = make(64, 6, boards, 2);
         run("x16<64,4> split, 6 x 64", k_trunk_x16<64, 4, 1, 0, 0, 0, 1>, Geo16<64, 4, 1>::lds_bytes(4), 4, 64, 6, boards, reps, d, ref, nullptr);
     }
     return 0;
