@@ -204,7 +204,7 @@ class ChessModel(object):
     #            (peaked policy, values spread over (-1, 1), unit-gain layers): 6e-3 .. 2.4e-2.
     #   "f16x3"  every operand carried as a hi + lo fp16 pair, three MFMAs per product
     #            (CRL_TRUNK_SPLIT): 3e-6 .. 8e-5 on every tower and weight set, the same as PyTorch's
-    #            fp32 convolutions, at 2.9x (64 filters), 3.1x (128) and 4.5x (256) the trunk time.
+    #            fp32 convolutions, at 2.5x (64 filters), 3.1x (128) and 3.6x (256) the trunk time.
     #   "auto"   (default: the 1e-3 bar of the drop-in contract comes first) decided per weight set
     #            when it is loaded: both modes evaluate a fixed probe set of positions (random playouts
     #            by the rules kernels) and "f16" is kept only if it stays within PROBE_TOL of "f16x3"
