@@ -58,14 +58,8 @@ struct Geo16 {
     static constexpr int AROW = AROW_CH * 2 + 32;
     static constexpr int ABOARD = 64 * AROW;
     static constexpr int ZERO_OFF = NB * ABOARD;
-    // 16 zero rows laid out like board rows (same bank residues).  The split kernels at 256 filters
-    // keep SHORT zero rows -- the stride of the unsplit row, 544 B; a read of the lo half, 512 B further,
-    // runs on into the following zero rows (all zeros, same residue mod 256) -- plus one spare row for
-    // the last of them: 9 KB instead of 17, which is what lets the five-slot ring (pair publishing) fit
-    static constexpr bool ZSHORT = SPLIT && F == 256;
-    static constexpr int ZSTRIDE = ZSHORT ? F * 2 + 32 : AROW;
-    static constexpr int ZERO_BYTES = (ZSHORT ? 17 : 16) * ZSTRIDE;
-    static_assert(!ZSHORT || 15 * ZSTRIDE + LO_OFF + (AROW_CH / 2) * 2 <= ZERO_BYTES, "lo reads stay inside the zero rows");
+    static constexpr int ZSTRIDE = AROW;                // 16 zero rows laid out like board rows (same bank residues)
+    static constexpr int ZERO_BYTES = 16 * ZSTRIDE;
     static constexpr int BIAS_OFF = ZERO_OFF + ZERO_BYTES;          // float [2][F]: this layer's and the next one's
     static constexpr int WRING_OFF = ((BIAS_OFF + 2 * F * 4 + 1023) / 1024) * 1024;
     static constexpr int LDS_BYTES = WRING_OFF + PIPE_RING * TILE_BYTES;

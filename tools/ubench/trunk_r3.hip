@@ -107,8 +107,7 @@ int main(int argc, char **argv)
         printf("== f16x3 (split operands), %d boards\n", boards);
         run("x16<128,2> pair split, 10 x 128", k_trunk_x16<128, 2, 1, 0, 1, 0, 1>, Geo16<128, 2, 1>::lds_bytes(5), 2, 128, 10, boards, reps, b, ref, nullptr);
         Bufs c = make(256, 20, boards, 2);
-        run("x16<256,1> split, ring of 4, 20 x 256", k_trunk_x16<256, 1, 1, 0, 0, 0, 1>, Geo16<256, 1, 1>::lds_bytes(4), 1, 256, 20, boards, 3, c, ref, nullptr);
-        run("x16<256,1> split, pair publishing, 20 x 256", k_trunk_x16<256, 1, 1, 0, 1, 0, 1>, Geo16<256, 1, 1>::lds_bytes(5), 1, 256, 20, boards, 3, c, out, &ref);
+        run("x16<256,1> split, 20 x 256", k_trunk_x16<256, 1, 1, 0, 0, 0, 1>, Geo16<256, 1, 1>::lds_bytes(4), 1, 256, 20, boards, 3, c, ref, nullptr);
         Bufs d = make(64, 6, boards, 2);
         run("x16<64,4> split, 6 x 64", k_trunk_x16<64, 4, 1, 0, 0, 0, 1>, Geo16<64, 4, 1>::lds_bytes(4), 4, 64, 6, boards, reps, d, ref, nullptr);
     }
