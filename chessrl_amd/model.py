@@ -223,6 +223,7 @@ class ChessModel(object):
         self.precision = None                    # resolved per weight set ("f16" / "f16x3"; the dtype otherwise)
         self.precision_probe = None              # what "auto" measured
         self.graph_epoch = 0                     # bumped when the kernel a captured graph holds changes
+        self._scratch = {}                       # batch size -> slice statistics of the small-batch heads
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
@@ -474,10 +475,8 @@ class ChessModel(object):
     def _heads_scratch(self, n_boards):
         """Slice statistics of the small-batch heads (crl_heads_forward: float [n_boards][16]); one
         buffer per batch size, kept, so that captured graphs hold a stable address."""
-        buf = self._scratch.get(n_boards) if hasattr(self, "_scratch") else None
+        buf = self._scratch.get(n_boards)
         if buf is None:
-            if not hasattr(self, "_scratch"):
-                self._scratch = {}
             buf = self._scratch[n_boards] = torch.zeros((n_boards, 16), dtype=torch.float32, device=self.device)
         return buf
 

@@ -129,7 +129,6 @@ def _rolling_worker(rank, world, port, q):
     log = []
 
     def on_round(r, recs):
-        t = dist.get_rank()
         gathered = records.gather_records(recs, max_plies=8)       # a collective inside the callback
         log.append((r, sorted(x.game_id for x in recs), [x.game_id for x in gathered]))
 

@@ -440,3 +440,40 @@ def test_rolling_rounds_play_the_same_games_and_hand_rounds_over_in_order():
     assert sorted(x.game_id for x in c.take_round(0)) == list(range(1, 64, 2))
     assert all(x == rb[x.game_id] for x in c.take_round(1))
     c.close()
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_cli_rolling_rounds_play_train_and_swap_weights_in_place(tmp_path, ranks):
+    """``--rolling``: two overlapping rounds of 6 games through the CLI -- records of both rounds in id
+    order per round, one training pass per round, the weights swapped in place under the running
+    engine (and broadcast to the second rank: torchrun x 2, gloo, both ranks on this GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "models")
+    args = ["-m", "chessrl_amd.selfplay", d, "--games", "6", "--sims", "4", "--blocks", "1", "--filters", "64",
+            "--rounds", "2", "--seed", "5", "--rolling", "--parallel", "4"]
+    env = dict(os.environ)
+    if ranks == 1:
+        cmd = [sys.executable] + args
+    else:
+        env.update(CRL_DIST_BACKEND="gloo", CRL_DEVICE="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40)] + args
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = json.load(open(os.path.join(d, "gameplays.json")))
+    assert len(recs) == 12 and all(g["result"] in (1, -1, 0) and len(g["moves"]) > 0 for g in recs)
+    log = [json.loads(l) for l in open(os.path.join(d, "train_log.jsonl"))]
+    assert len(log) == 2 and all(np.isfinite(e["loss"]) for e in log)
+    # round 0 is played on the initial weights until it is handed over: its first games (which end
+    # before any training) are the games of a plain run with the same seed
+    one = str(tmp_path / "plain")
+    r1 = subprocess.run([sys.executable, "-m", "chessrl_amd.selfplay", one, "--games", "12", "--sims", "4",
+                         "--blocks", "1", "--filters", "64", "--seed", "5", "--no-train", "--parallel", "4"],
+                        cwd=root, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    plain = json.load(open(os.path.join(one, "gameplays.json")))
+    assert [g["moves"] for g in recs[:6]] == [g["moves"] for g in plain[:6]]
