@@ -477,3 +477,29 @@ def test_cli_rolling_rounds_play_train_and_swap_weights_in_place(tmp_path, ranks
     assert r1.returncode == 0, r1.stderr[-2000:]
     plain = json.load(open(os.path.join(one, "gameplays.json")))
     assert [g["moves"] for g in recs[:6]] == [g["moves"] for g in plain[:6]]
+
+
+def test_stepwise_driving_plays_the_same_games_as_whole_moves():
+    """bench.py drives the runner one lockstep step at a time (``step()``: the Dirichlet noise of a
+    move is drawn half-way through it, while the GPU works); ``run()`` drives whole moves.  Same games,
+    and both equal the oracle's."""
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=21, prior_shift=30)
+    kw = dict(n_parallel=5, sims=6, seed=5, noise=True, total_games=9, max_plies=2048)
+    a = SelfPlayRunner(net.to("cuda:0"), **kw)
+    whole = {r.game_id: r for r in a.run()}
+    a.close()
+    b = SelfPlayRunner(net.to("cuda:0"), **kw)
+    steps = 0
+    while b.active().any():
+        b.step()
+        steps += 1
+    stepwise = {r.game_id: r for r in b.finished}
+    assert b.engine.ctx.counters()["sims"] == b.sims_run and steps % 6 == 0
+    b.close()
+    assert sorted(whole) == sorted(stepwise) == list(range(9))
+    for k in whole:
+        assert whole[k] == stepwise[k], k
+    for k in (0, 4, 8):
+        g = oracle_game(net, k, 5, 6, True)
+        assert stepwise[k].get_history()["moves"] == g.get_history()["moves"] and stepwise[k].result == g.get_result()
