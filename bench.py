@@ -97,14 +97,17 @@ def visible_gpus():
         nodes = sorted(os.listdir(base), key=int)
     except (OSError, ValueError):
         return None
-    n = 0
+    n, readable = 0, 0
     for node in nodes:
         try:
             props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if line.strip())
-        except OSError:
+        except (OSError, ValueError):
             continue
+        readable += 1
         if int(props.get("simd_count", "0")) > 0:
             n += 1
+    if readable == 0:
+        return None                                          # topology not readable here: let the ranks find out
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
