@@ -287,9 +287,13 @@ def test_cli_plays_and_trains_rounds(tmp_path):
     assert len(log) == 2 and all(np.isfinite(e["loss"]) for e in log)
     w = dict(np.load(os.path.join(d, "model-0.npz")))
     assert int(w["meta.blocks"]) == 1 and int(w["meta.filters"]) == 64
-    # a second invocation picks the saved model up (get_model_path) and only plays
-    r = subprocess.run(cmd[:-4] + ["--no-train"], cwd=root, capture_output=True, text=True, timeout=600)
+    # a second invocation picks the saved model up (get_model_path) and only plays; the arithmetic
+    # knobs of the CLI: the reference's pinned-numpy PUCT product and a pinned tower precision
+    r = subprocess.run(cmd[:-4] + ["--no-train", "--numpy-promotion", "legacy", "--precision", "f16x3"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    bad = subprocess.run(cmd[:-4] + ["--no-train", "--precision", "fp64"], cwd=root, capture_output=True, text=True)
+    assert bad.returncode != 0 and "invalid choice" in bad.stderr
     assert np.array_equal(dict(np.load(os.path.join(d, "model-0.npz")))["stem.kernel"], w["stem.kernel"])
 
 
