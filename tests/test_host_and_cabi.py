@@ -326,3 +326,22 @@ def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(tmp_path
     kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
     assert len(kernels) >= 20, r.stdout                       # every dispatched (F, NB, BITS, PAIR, GROUP, SPLIT)
     assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
+
+
+def test_dataset_accepts_game_records_and_refuses_unknown_entries():
+    """DatasetGame.append / += take a slot-free GameRecord (anything answering get_history()) like a
+    Game, another dataset's games, and raise on anything else instead of dropping it silently."""
+    from chessrl_amd import records
+    from chessrl_amd.dataset import DatasetGame
+    from chessrl_amd.game import uci_to_move
+    rec = records.GameRecord(3, [uci_to_move(u) for u in ["e2e4", "e7e5"]], 1, True, "d")
+    ds = DatasetGame()
+    ds.append(rec)
+    ds += rec
+    other = DatasetGame([rec])
+    ds += other
+    assert len(ds) == 3 and json.loads(str(ds))[0]["moves"] == ["e2e4", "e7e5"]
+    with pytest.raises(TypeError):
+        ds.append({"moves": ["e2e4"]})
+    with pytest.raises(TypeError):
+        ds += 5
