@@ -147,8 +147,11 @@ class Game(object):
     BLACK = False
 
     def __init__(self, board=None, player_color=True, date=None):
-        """``board``: None (standard start), a FEN string, or another ``Game`` to deep-copy
-        (the reference passes a ``chess.Board``; python-chess does not exist here)."""
+        """``board``: None (standard start), a FEN string, a ``crl_board`` row, another ``Game`` to
+        deep-copy, or -- what the reference passes (game.py:17-21) -- a python-chess ``chess.Board``,
+        recognised by duck typing (``root()``, ``fen()``, ``move_stack`` of moves with ``uci()``; nothing
+        is imported): the game starts from the board's root position and its move stack is replayed
+        through the rules kernels, so history planes and repetition counts are the board's."""
         a = arena()
         self._slot = a.alloc()
         if isinstance(board, Game):
@@ -157,6 +160,19 @@ class Game(object):
             a.one(self._slot).set_positions(board_row_from_fen(board)[None])
         elif board is None:
             a.one(self._slot).reset_games()
+        elif callable(getattr(board, "fen", None)) and hasattr(board, "move_stack"):
+            root = board.root() if callable(getattr(board, "root", None)) else None
+            stack = list(board.move_stack)
+            if root is None and stack:
+                a.release(self._slot)
+                self._slot = None
+                raise TypeError("a board with a move stack must offer root() (python-chess does)")
+            a.one(self._slot).set_positions(board_row_from_fen((root or board).fen())[None])
+            for mv in stack:
+                if not self.move(mv.uci() if callable(getattr(mv, "uci", None)) else str(mv)):
+                    a.release(self._slot)
+                    self._slot = None
+                    raise ValueError("move stack of the board does not replay: %s" % mv)
         else:
             a.one(self._slot).set_positions(np.asarray(board, dtype=np.uint64).reshape(1, 8))
         self.player_color = player_color

@@ -109,6 +109,31 @@ def test_dropin_objects_match_oracle():
                           encoder_oracle.get_game_state(og, flipped=True))
     c = g.get_copy()
     assert c.move("b8c6") and len(c) == 6 and len(g) == 5          # deep copy incl. move stack
+
+    class _Move(object):                                           # what a python-chess Board looks like from outside
+        def __init__(self, u):
+            self.u = u
+
+        def uci(self):
+            return self.u
+
+    class _Board(object):
+        def __init__(self, fen, moves):
+            self._fen, self.move_stack = fen, [_Move(u) for u in moves]
+
+        def root(self):
+            return _Board(self._fen, [])
+
+        def fen(self):
+            return self._fen
+
+    start = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+    gb = Game(board=_Board(start, ["e2e4", "c7c5", "g1f3", "d7d6", "f1b5"]))     # game.py:17-21
+    assert len(gb) == 5 and gb.get_fen() == g.get_fen() and gb.get_legal_moves() == g.get_legal_moves()
+    assert np.array_equal(netencoder.get_game_state(gb), netencoder.get_game_state(g))   # history planes too
+    with pytest.raises(ValueError):
+        Game(board=_Board(start, ["e2e5"]))
+    gb.free()
     assert c.get_history()["moves"][:5] == g.get_history()["moves"]
     # predict_* / best_move(real_game=True)
     assert np.array_equal(np.array(agent.predict_policy(g), dtype=np.float32),
