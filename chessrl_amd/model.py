@@ -210,7 +210,7 @@ class ChessModel(object):
     #            by the rules kernels) and "f16" is kept only if it stays within PROBE_TOL of "f16x3"
     #            on all of them (the maximum over thousands of real positions is up to 1.7x the probe's).
     PRECISIONS = ("auto", "f16", "f16x3")
-    PROBE_TOL = 6e-4
+    PROBE_TOL = 5e-4
     PROBE_POSITIONS = 256
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
