@@ -174,6 +174,16 @@ __device__ inline void dev_error(const Dev &d, int code)
     atomicCAS(d.err, 0, code);
 }
 
+// Descent hint kept in the spare word of an edge record.  get_best_child needs, of the node it descends
+// into, the slot of its edge records and their number -- both in that node's own record, i.e. behind a
+// second dependent HBM read per tree level.  Once a node is fully expanded (from then on select only ever
+// scans it, mctree.py:216-231) those two numbers are frozen, so they are copied into the parent's edge
+// record, which the scan of the level above has just read: one dependent read per level instead of two.
+constexpr u32 HINT_FULL = 1u << 31;
+constexpr int HINT_EDGE_BITS = 23;                 // edge slots per game < 2^23 (38 000 simulations per move)
+__device__ inline u32 hint_pack(int edge0, int nmoves) { return HINT_FULL | ((u32)nmoves << HINT_EDGE_BITS) | (u32)edge0; }
+static_assert(MAX_BRANCH < 256, "nmoves fits the hint");
+
 __device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, const u16 *mv, int lane)
 {
     for (int j = lane; j < n; j += 64) {
@@ -529,10 +539,15 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
     const bool legacy = (d.flags & 1u) != 0;
     const int p = uni(d.game[g].ply);
     int node = 0, level = 0;
+    int edge0 = 0, nmoves = 0, nexp = 0, result = RESULT_NONE, parent_edge = -1;
+    bool need_meta = true;                                             // false: the parent's edge record said it all
+    if (d.ECAP >= (1 << HINT_EDGE_BITS)) { dev_error(d, DERR_EDGE_POOL); return; }   // edge slots fit the hint
     for (;;) {
-        NodeMeta m = d.node[nb + node].meta;
-        const int edge0 = uni(m.edge0), nmoves = uni(m.nmoves), nexp = uni(m.nexp);
-        const int result = uni(m.result);
+        if (need_meta) {
+            NodeMeta m = d.node[nb + node].meta;
+            edge0 = uni(m.edge0); nmoves = uni(m.nmoves); nexp = uni(m.nexp);
+            result = uni(m.result); parent_edge = uni(m.parent_edge);
+        }
         if (result != RESULT_NONE) {                                   // is_terminal_state
             if (lane == 0) { d.game[g].leaf_kind = LEAF_TERMINAL_HIT; d.game[g].leaf_node = node; }
             break;
@@ -545,6 +560,8 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
             if (c >= d.N || level + 1 >= d.N) { dev_error(d, DERR_NODE_POOL); break; }
             if (lane == 0) {
                 d.node[nb + node].meta.nexp = (u16)(nexp + 1);
+                if (nexp + 1 == nmoves && parent_edge >= 0)            // fully expanded from now on: leave the hint
+                    d.edge[eb + parent_edge].pad = hint_pack(edge0, nmoves);
                 d.path_edge[nb + level] = edge;
                 d.path_node[nb + level + 1] = (u16)c;
                 d.game[g].n_nodes = c + 1;
@@ -587,6 +604,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
         // i.e. the LARGEST legal index among equals
         double best = -__builtin_inf();
         int bj = -1, bchild = 0;
+        u32 bhint = 0;
         for (int base = 0; base < nmoves; base += 64) {
             const int j = base + lane;
             if (j < nmoves) {
@@ -600,7 +618,7 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
                                          : (double)__fmul_rn(10.0f, e.prior);
                 const double u = __dmul_rn(cp, __ddiv_rn(__dsqrt_rn(sumv), den));
                 const double sc = __dadd_rn(q, u);
-                if (bj < 0 || sc > best || (sc == best && j > bj)) { best = sc; bj = j; bchild = e.child; }
+                if (bj < 0 || sc > best || (sc == best && j > bj)) { best = sc; bj = j; bchild = e.child; bhint = e.pad; }
             }
         }
 #pragma unroll
@@ -608,8 +626,9 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
             const double ob = __shfl_xor(best, o);
             const int oj = __shfl_xor(bj, o);
             const int oc = __shfl_xor(bchild, o);
+            const u32 oh = __shfl_xor(bhint, o);
             const bool take = oj >= 0 && (bj < 0 || ob > best || (ob == best && oj > bj));
-            if (take) { best = ob; bj = oj; bchild = oc; }
+            if (take) { best = ob; bj = oj; bchild = oc; bhint = oh; }
         }
         bj = uni(bj);
         const int edge = edge0 + bj;
@@ -621,6 +640,17 @@ __global__ __launch_bounds__(64, 4) void k_select_expand(Dev d, const float *pol
         }
         level++;
         node = uni(child);
+        const u32 hint = uni(bhint);
+        if (uni(bchild) & CHILD_TERMINAL) {                            // the child's state ended the game: as its
+            need_meta = false;                                         // record would say (result != RESULT_NONE)
+            result = 0;                                                // any value but RESULT_NONE: only tested
+        } else if (hint & HINT_FULL) {                                 // fully expanded: straight to its edge records
+            need_meta = false;
+            edge0 = (int)(hint & ((1u << HINT_EDGE_BITS) - 1)); nmoves = (int)((hint >> HINT_EDGE_BITS) & 0xFFu); nexp = nmoves;
+            result = RESULT_NONE;
+        } else {
+            need_meta = true;
+        }
     }
     if (lane == 0) d.game[g].path_len = level;
 }

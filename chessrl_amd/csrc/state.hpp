@@ -84,7 +84,9 @@ struct __attribute__((aligned(8))) Edge {
     float prior;            // child's prior (1 until the parent is fully expanded)
     u16 move;               // the move (u16 id)
     u16 child;              // child node id | CHILD_TERMINAL, CHILD_NONE while unexpanded
-    uint32_t pad;
+    uint32_t pad;           // descent hint (search.hpp: hint_pack): 0, or -- once the CHILD is fully expanded --
+                            // HINT_FULL | the child's nmoves << 23 | the child's edge0: select then goes on to the
+                            // child's edge records without reading the child's node record first
 };
 static_assert(sizeof(Edge) == 24, "Edge must be 24 bytes");
 
