@@ -1,8 +1,10 @@
 #!/bin/bash
-# Scratch (GPU): the parity tests of the search / rules / self-play kernels while a second process keeps the
-# GPU busy (tools/trunk_stability_probe.py disturb): results that depend on timing show up as failures.
+# Scratch (GPU): the -m gpu parity tests while a second process keeps the GPU busy
+# (tools/trunk_stability_probe.py disturb): results that depend on timing show up as failures.
+#   bash tools/disturbed_suite.sh [pytest files ...]     (default: rules, search, self-play)
 cd $GRAFT_REPO_ROOT
 python tools/trunk_stability_probe.py disturb 100000 > /dev/null 2>&1 &
 D=$!
-python -m pytest tests/test_gpu_rules.py tests/test_gpu_search.py tests/test_gpu_selfplay.py -q -x -m gpu 2>&1 | tail -5
+FILES=${@:-tests/test_gpu_rules.py tests/test_gpu_search.py tests/test_gpu_selfplay.py}
+python -m pytest $FILES -q -x -m gpu 2>&1 | tail -5
 kill $D; wait $D 2>/dev/null
