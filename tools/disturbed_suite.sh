@@ -7,4 +7,6 @@ python tools/trunk_stability_probe.py disturb 100000 > /dev/null 2>&1 &
 D=$!
 FILES=${@:-tests/test_gpu_rules.py tests/test_gpu_search.py tests/test_gpu_selfplay.py}
 python -m pytest $FILES -q -x -m gpu 2>&1 | tail -5
+RC=${PIPESTATUS[0]}
 kill $D; wait $D 2>/dev/null
+exit $RC
