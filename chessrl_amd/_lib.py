@@ -39,6 +39,7 @@ PLANES = 128
 NO_MOVE = 0xFFFF
 RESULT_NONE = 2
 FLAG_NUMPY_LEGACY = 1
+POLICY_FULL, POLICY_LEGAL, POLICY_LEGAL_RAW = 0, 1, 2
 TRUNK_BITPLANES = 1
 TRUNK_SPLIT = 2
 
@@ -50,9 +51,10 @@ SYMBOLS = [
     "crl_get_positions", "crl_legal_moves", "crl_push_moves", "crl_push_sequences", "crl_results", "crl_records",
     "crl_encode", "crl_greedy_moves", "crl_search_begin", "crl_search_root_priors",
     "crl_sim_select_expand", "crl_sim_reply", "crl_sim_backup", "crl_root_children",
-    "crl_advance", "crl_counters", "crl_trunk128_forward", "crl_trunk_forward",
+    "crl_advance", "crl_counters", "crl_trunk_forward",
     "crl_trunk_forward_bitplanes", "crl_trunk_forward_x", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
-    "crl_heads_forward_legal", "crl_heads_set_sliced_max",
+    "crl_heads_forward_legal", "crl_heads_forward_legal_raw", "crl_heads_raw_supported", "crl_heads_set_sliced_max",
+    "crl_set_policy_stats", "crl_abi_version", "crl_source_hash",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -61,50 +63,63 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-def _stamp(so):
-    return so + ".srchash"
+ABI_VERSION = 4          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
+_HASH_MARK = b"CRL_SRC_HASH="
+
+
+def embedded_hash(so=SO_PATH):
+    """The source hash compiled INTO the library (csrc/api.hip: g_source_hash), read from the file
+    without loading it; None when the file is missing or carries no marker."""
+    try:
+        data = open(so, "rb").read()
+    except OSError:
+        return None
+    i = data.find(_HASH_MARK)
+    if i < 0:
+        return None
+    tail = data[i + len(_HASH_MARK):i + len(_HASH_MARK) + 64]
+    return tail.split(b"\0")[0].decode("ascii", "replace")
+
+
+def have_sources():
+    return os.path.isdir(_CSRC) and os.path.exists(HEADER)
 
 
 def is_stale(so=SO_PATH):
-    """True when `so` is missing or its stamp says it was compiled from other sources than the
-    ones present (the build leaves the sources' sha256 next to the library).  A library WITHOUT a
-    stamp (a deploy copy that left the untracked ``*.srchash`` behind) is not stale: it is loaded
-    as shipped, see ``lib()``."""
+    """True when `so` is missing or was compiled from other sources than the ones present: the
+    library carries the sha256 of its sources inside (no side file that a deploy can lose or an
+    interrupted build can leave behind).  A deploy of the library WITHOUT csrc/ has nothing to be
+    compared with and is taken as shipped."""
     if not os.path.exists(so):
         return True
-    if not os.path.exists(_stamp(so)):
+    if not have_sources():
         return False
-    return open(_stamp(so)).read().strip() != source_hash()
+    return embedded_hash(so) != source_hash()
 
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> chessrl_amd/libchessrl_hip.so (in-tree; works without a GPU).
-    Recompiles whenever any file of csrc/ or the header changed since the library was built, or
-    when the library carries no stamp (``force`` recompiles regardless)."""
+    Recompiles whenever any file of csrc/ or the header changed since the library was built
+    (``force`` recompiles regardless).  The sources' hash is compiled in (``crl_source_hash``)."""
     so = SO_PATH
-    fresh = lambda: os.path.exists(_stamp(so)) and not is_stale(so)
-    if not force and fresh():
+    if not force and not is_stale(so):
         return so
     # several ranks of one node may arrive here together (torchrun starts one process per GPU):
-    # one compiles, the others wait on the lock and find the library fresh; the library and its
-    # stamp appear atomically (rename), so nobody ever loads a half-written file
+    # one compiles, the others wait on the lock and find the library fresh; the library appears
+    # atomically (rename), so nobody ever loads a half-written file
     import fcntl
     with open(so + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and fresh():
+        if not force and not is_stale(so):
             return so
         tmp = "%s.tmp.%d" % (so, os.getpid())
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", tmp, os.path.join(_CSRC, "api.hip")]
+        cmd = (["hipcc"] + HIPCC_FLAGS + ['-DCRL_SOURCE_HASH="%s"' % source_hash()] +
+               ["-o", tmp, os.path.join(_CSRC, "api.hip")])
         if verbose:
             print(" ".join(cmd))
         try:
             subprocess.check_call(cmd)
-            if os.path.exists(_stamp(so)):
-                os.remove(_stamp(so))
             os.replace(tmp, so)
-            with open(_stamp(so) + ".tmp", "w") as f:
-                f.write(source_hash() + "\n")
-            os.replace(_stamp(so) + ".tmp", _stamp(so))
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
@@ -115,9 +130,10 @@ _lib = None
 
 
 def lib():
-    """Load the shared library.  It is compiled first when it is missing or its stamp shows it is
-    older than csrc/; a library without a stamp, or a stale one on a box without hipcc, is loaded
-    as shipped with a warning.  No CPU fallback: without a loadable library this raises."""
+    """Load the shared library.  It is compiled first when it is missing or was built from other
+    sources than the csrc/ present; a stale library that cannot be rebuilt is REFUSED (its entry points
+    may have other signatures than this binding's), and so is a library of another ABI version.  No
+    CPU fallback: without a loadable library this raises."""
     global _lib
     if _lib is not None:
         return _lib
@@ -129,21 +145,25 @@ def lib():
         try:
             build()
         except Exception as e:  # pragma: no cover
-            if not os.path.exists(so):
-                raise HipLibraryError(
-                    "%s is missing and could not be built with hipcc (%s); "
-                    "the HIP path has no CPU fallback" % (os.path.basename(so), e))
-            import warnings
-            warnings.warn("%s is older than csrc/ and could not be rebuilt with hipcc (%s): loading it "
-                          "as shipped" % (os.path.basename(so), e))
-    elif not os.path.exists(_stamp(so)):
-        import warnings
-        warnings.warn("%s carries no source stamp (*.srchash was not deployed with it): loading it as "
-                      "shipped, freshness against csrc/ unchecked" % os.path.basename(so))
+            raise HipLibraryError(
+                "%s is %s and could not be built with hipcc (%s); the HIP path has no CPU fallback and a "
+                "library built from other sources is not loaded"
+                % (os.path.basename(so), "missing" if not os.path.exists(so) else "older than csrc/", e))
     try:
         L = ctypes.CDLL(so)
     except OSError as e:
         raise HipLibraryError("cannot load %s: %s" % (so, e))
+    try:
+        L.crl_abi_version.restype = ctypes.c_int
+        L.crl_source_hash.restype = ctypes.c_char_p
+        abi, built_from = L.crl_abi_version(), (L.crl_source_hash() or b"").decode()
+    except AttributeError:
+        raise HipLibraryError("%s exports no crl_abi_version: it predates this binding" % so)
+    if abi != ABI_VERSION:
+        raise HipLibraryError("%s has ABI version %d, this binding needs %d" % (so, abi, ABI_VERSION))
+    if have_sources() and built_from != source_hash():
+        raise HipLibraryError("%s was built from other sources (%s...) than csrc/ (%s...)"
+                              % (so, built_from[:12], source_hash()[:12]))
     vp, i32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
     L.crl_create.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, u32]
     L.crl_destroy.argtypes = [vp]
@@ -176,7 +196,6 @@ def lib():
     L.crl_root_children.argtypes = [vp] * 8
     L.crl_advance.argtypes = [vp, vp, vp, vp]
     L.crl_counters.argtypes = [vp, vp]
-    L.crl_trunk128_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -185,13 +204,16 @@ def lib():
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]
     L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.crl_heads_forward_legal.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_forward_legal_raw.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.crl_heads_raw_supported.argtypes = [i32]
     L.crl_heads_set_sliced_max.argtypes = [i32]
     L.crl_set_policy_format.argtypes = [vp, i32]
+    L.crl_set_policy_stats.argtypes = [vp, i32, vp]
     L.crl_eval_labels.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     for name in SYMBOLS:
-        if name not in ("crl_destroy", "crl_last_error"):
+        if name not in ("crl_destroy", "crl_last_error", "crl_source_hash"):
             getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -249,9 +271,14 @@ class Context(object):
         self.G = count
 
     def set_policy_format(self, legal):
-        """legal=True: the simulation entry points take priors[row][256] of the legal moves
-        (CRL_POLICY_LEGAL) instead of full policy[row][1968] rows."""
-        self._ck(self._L.crl_set_policy_format(self._h, 1 if legal else 0), "crl_set_policy_format")
+        """What the simulation entry points take as "policy": False / 0 = full policy[row][1968] rows,
+        True / 1 = priors[row][256] of the legal moves (CRL_POLICY_LEGAL), 2 = the same rows holding
+        logits that the kernels normalise on read (CRL_POLICY_LEGAL_RAW; ``set_policy_stats`` first)."""
+        self._ck(self._L.crl_set_policy_format(self._h, int(legal)), "crl_set_policy_format")
+
+    def set_policy_stats(self, which, dev_stats):
+        """Device address of the slice statistics (float [rows][16]) of tower call ``which`` (0: S1, 1: S2)."""
+        self._ck(self._L.crl_set_policy_stats(self._h, which, ctypes.c_void_p(dev_stats)), "crl_set_policy_stats")
 
     def eval_labels(self, which):
         """(labels, counts) device addresses for the position tower call `which` evaluates

@@ -23,6 +23,13 @@ static_assert(CRL_MAX_MOVES == MAX_MOVES && CRL_N_LABELS == N_LABELS && CRL_PLAN
 
 static thread_local std::string g_create_error;
 
+// sha256 of the sources this library was compiled from (chessrl_amd/_lib.py passes it at build time; the
+// marker makes it findable in the file without loading it)
+#ifndef CRL_SOURCE_HASH
+#define CRL_SOURCE_HASH "unstamped"
+#endif
+static const char g_source_hash[] = "CRL_SRC_HASH=" CRL_SOURCE_HASH;
+
 struct crl_ctx {
     int device = 0;
     int W = 0;                    // slots in the active window [d.g0, d.g0 + W)
@@ -165,6 +172,7 @@ int crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_p
     d.g0 = 0;
     d.plane_fmt = CRL_PLANES_F16;
     d.policy_fmt = CRL_POLICY_FULL;
+    d.stats_s1 = d.stats_s2 = nullptr;
     ctx->W = max_games;
     const size_t G = d.G, GN = G * d.N, GE = G * (size_t)d.ECAP;
     bool ok = true;
@@ -254,9 +262,19 @@ int crl_set_plane_format(crl_ctx *ctx, int format)
 
 int crl_set_policy_format(crl_ctx *ctx, int format)
 {
-    if (!ctx || (format != CRL_POLICY_FULL && format != CRL_POLICY_LEGAL))
+    if (!ctx || (format != CRL_POLICY_FULL && format != CRL_POLICY_LEGAL && format != CRL_POLICY_LEGAL_RAW))
         return fail(ctx, CRL_ERR_ARG, "crl_set_policy_format: bad argument");
+    if (format == CRL_POLICY_LEGAL_RAW && (!ctx->d.stats_s1 || !ctx->d.stats_s2))
+        return fail(ctx, CRL_ERR_STATE, "crl_set_policy_format: CRL_POLICY_LEGAL_RAW needs crl_set_policy_stats for both evaluations first");
     ctx->d.policy_fmt = format;
+    return CRL_OK;
+}
+
+int crl_set_policy_stats(crl_ctx *ctx, int which, const void *dev_stats_f32)
+{
+    if (!ctx || (which != 0 && which != 1) || !dev_stats_f32)
+        return fail(ctx, CRL_ERR_ARG, "crl_set_policy_stats: bad argument");
+    (which ? ctx->d.stats_s2 : ctx->d.stats_s1) = (const float2 *)dev_stats_f32;
     return CRL_OK;
 }
 
@@ -296,6 +314,8 @@ int crl_copy_game_from(crl_ctx *ctx, int dst, crl_ctx *src_ctx, int src)
 }
 
 const char *crl_last_error(crl_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+const char *crl_source_hash(void) { return g_source_hash + 13; }
+int crl_abi_version(void) { return CRL_ABI_VERSION; }
 int crl_max_games(crl_ctx *ctx) { return ctx ? ctx->d.G : CRL_ERR_ARG; }
 int crl_max_sims(crl_ctx *ctx) { return ctx ? ctx->d.N - 1 : CRL_ERR_ARG; }
 
@@ -532,14 +552,6 @@ int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
                       int n_boards, int n_blocks, const void *dev_head_w_f32,
                       const void *dev_head_b_f32, void *dev_head_out_f32);
 
-int crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const void *dev_wtiles_f16,
-                         const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
-                         const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32)
-{
-    return crl_trunk_forward(hip_stream, 128, dev_planes_f16, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
-                             n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
-}
-
 // small batches run half-size workgroups (see below); crl_trunk_set_small_batch turns that off
 static std::atomic<int> g_small_batch{1};
 
@@ -687,25 +699,32 @@ int crl_heads_set_sliced_max(int boards)
     return CRL_OK;
 }
 
+static bool heads_sliced(int n_boards) { return n_boards <= g_sliced_max.load(); }
+
+// raw: (LEGAL, sliced path only) leave the LOGITS in the priors rows and the slice statistics in the scratch;
+// the consumers normalise on read (CRL_POLICY_LEGAL_RAW) and the normalising pass is not launched
 static int heads_forward(void *hip_stream, const void *act, int n_boards, const void *pol_wp, const void *pol_bias,
                          const void *val_w1p, const void *val_b1, const void *val_w2b2, const uint16_t *labels,
-                         const int32_t *counts, void *pol_out, void *val_out, void *scratch, bool legal,
+                         const int32_t *counts, void *pol_out, void *val_out, void *scratch, bool legal, bool raw,
                          const char *who)
 {
     if (!act || n_boards < 1 || !pol_wp || !pol_bias || !pol_out || (legal && (!labels || !counts)) ||
         (val_out && (!val_w1p || !val_b1 || !val_w2b2)))
         return fail(nullptr, CRL_ERR_ARG, who);
+    if (raw && (!scratch || !heads_sliced(n_boards)))
+        return fail(nullptr, CRL_ERR_ARG, "crl_heads_forward_legal_raw: needs the scratch and a batch the sliced heads serve (crl_heads_raw_supported)");
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned blocks = (unsigned)((n_boards + 15) / 16);
-    if (scratch && n_boards <= g_sliced_max.load()) {
+    if (scratch && heads_sliced(n_boards)) {
         const dim3 grid(crl_heads::N_SLICES + (val_out ? 1 : 0), blocks);
         if (legal) {
             hipLaunchKernelGGL(crl_heads::k_heads_sliced<true>, grid, dim3(256), 0, st, (const float *)act, n_boards,
                                (const unsigned char *)pol_wp, (const float *)pol_bias, (float *)pol_out, (float2 *)scratch,
                                (const unsigned short *)labels, (const int *)counts, (const unsigned char *)val_w1p,
                                (const float *)val_b1, (const float *)val_w2b2, (float *)val_out);
-            hipLaunchKernelGGL(crl_heads::k_policy_normalise<true>, dim3((n_boards + 3) / 4), dim3(256), 0, st,
-                               (float *)pol_out, (const float2 *)scratch, n_boards, (const int *)counts);
+            if (!raw)
+                hipLaunchKernelGGL(crl_heads::k_policy_normalise<true>, dim3((n_boards + 3) / 4), dim3(256), 0, st,
+                                   (float *)pol_out, (const float2 *)scratch, n_boards, (const int *)counts);
         } else {
             hipLaunchKernelGGL(crl_heads::k_heads_sliced<false>, grid, dim3(256), 0, st, (const float *)act, n_boards,
                                (const unsigned char *)pol_wp, (const float *)pol_bias, (float *)pol_out, (float2 *)scratch,
@@ -715,27 +734,31 @@ static int heads_forward(void *hip_stream, const void *act, int n_boards, const 
                                (float *)pol_out, (const float2 *)scratch, n_boards, (const int *)nullptr);
         }
     } else {
+        // one launch: the value head rides along as extra workgroups behind the policy's (8 board blocks each)
+        const unsigned vblocks = val_out ? (blocks + 7) / 8 : 0;
         if (legal) {
             auto kern = crl_heads::k_policy_head<1, true>;
             hipError_t ea = allow_big_lds((const void *)kern, crl_heads::LEGAL_LDS_BYTES);
             if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), crl_heads::LEGAL_LDS_BYTES, st,
+            hipLaunchKernelGGL(kern, dim3(blocks + vblocks), dim3(512), crl_heads::LEGAL_LDS_BYTES, st,
                                (const float *)act, n_boards, (const unsigned char *)pol_wp, (const float *)pol_bias,
-                               (float *)pol_out, (const unsigned short *)labels, (const int *)counts);
+                               (float *)pol_out, (const unsigned short *)labels, (const int *)counts, (int)blocks,
+                               (const unsigned char *)val_w1p, (const float *)val_b1, (const float *)val_w2b2,
+                               (float *)val_out);
         } else {
-            hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks), dim3(512), 0, st,
+            hipLaunchKernelGGL(crl_heads::k_policy_head<1>, dim3(blocks + vblocks), dim3(512), 0, st,
                                (const float *)act, n_boards, (const unsigned char *)pol_wp, (const float *)pol_bias,
-                               (float *)pol_out);
+                               (float *)pol_out, (const unsigned short *)nullptr, (const int *)nullptr, (int)blocks,
+                               (const unsigned char *)val_w1p, (const float *)val_b1, (const float *)val_w2b2,
+                               (float *)val_out);
         }
-        if (val_out)
-            hipLaunchKernelGGL(crl_heads::k_value_head, dim3(blocks), dim3(64), 0, st,
-                               (const float *)act, n_boards, (const unsigned char *)val_w1p, (const float *)val_b1,
-                               (const float *)val_w2b2, (float *)val_out);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
 }
+
+int crl_heads_raw_supported(int n_boards) { return n_boards >= 1 && heads_sliced(n_boards) ? 1 : 0; }
 
 int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boards,
                       const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
@@ -745,7 +768,7 @@ int crl_heads_forward(void *hip_stream, const void *dev_head_act_f32, int n_boar
 {
     return heads_forward(hip_stream, dev_head_act_f32, n_boards, dev_policy_wp_f16, dev_policy_bias_f32,
                          dev_value_w1p_f16, dev_value_b1_f32, dev_value_w2b2_f32, nullptr, nullptr,
-                         dev_policy_out_f32, dev_value_out_f32, dev_scratch_f32, false, "crl_heads_forward: bad argument");
+                         dev_policy_out_f32, dev_value_out_f32, dev_scratch_f32, false, false, "crl_heads_forward: bad argument");
 }
 
 int crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int n_boards,
@@ -757,8 +780,21 @@ int crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int 
 {
     return heads_forward(hip_stream, dev_head_act_f32, n_boards, dev_policy_wp_f16, dev_policy_bias_f32,
                          dev_value_w1p_f16, dev_value_b1_f32, dev_value_w2b2_f32, dev_labels, dev_counts,
-                         dev_priors_out_f32, dev_value_out_f32, dev_scratch_f32, true,
+                         dev_priors_out_f32, dev_value_out_f32, dev_scratch_f32, true, false,
                          "crl_heads_forward_legal: bad argument");
+}
+
+int crl_heads_forward_legal_raw(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                                const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                                const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                                const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
+                                const int32_t *dev_counts, void *dev_logits_out_f32, void *dev_value_out_f32,
+                                void *dev_stats_out_f32)
+{
+    return heads_forward(hip_stream, dev_head_act_f32, n_boards, dev_policy_wp_f16, dev_policy_bias_f32,
+                         dev_value_w1p_f16, dev_value_b1_f32, dev_value_w2b2_f32, dev_labels, dev_counts,
+                         dev_logits_out_f32, dev_value_out_f32, dev_stats_out_f32, true, true,
+                         "crl_heads_forward_legal_raw: bad argument");
 }
 
 static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, int channels, bool forward)

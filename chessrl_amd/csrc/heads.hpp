@@ -17,6 +17,7 @@
 // weight operand is packed on the host in fragment order [tile][k-step][hi|lo][lane][8 halves] (one
 // coalesced 1-KiB load per fragment, served by L2); the activation operand is split in-kernel.
 #pragma once
+#include "slices.hpp"
 #include "tower_common.hpp"
 
 namespace crl_heads {
@@ -49,6 +50,51 @@ __device__ __forceinline__ void split_act(const float *row, bool valid, int k, h
     }
 }
 
+// ---- value head: tanh(relu(h[64] . W1[64][256] + b1) . W2[256] + b2) -> value[n] -------------------
+// One wavefront per 16 boards (block `vblock`).
+__device__ __forceinline__ void value_head_block(const float *__restrict__ act, int n_boards, int vblock,
+                                                 const unsigned char *__restrict__ w1p,    // packed fp16
+                                                 const float *__restrict__ b1,
+                                                 const float *__restrict__ w2,             // [257]: w2, then b2
+                                                 float *__restrict__ value, int lane)
+{
+    const int r = lane & 15, q = lane >> 4;
+    const int board = vblock * 16 + r;
+    const bool valid = board < n_boards;
+    const float *row = act + (size_t)board * ACT + 128;
+    half8 hhi[2], hlo[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
+    const half8 *wf = reinterpret_cast<const half8 *>(w1p) + lane;
+    float z = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 16; jt++) {
+        f32x4h d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const half8 ahi = wf[((jt * 2 + s) * 2 + 0) * 64], alo = wf[((jt * 2 + s) * 2 + 1) * 64];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, hhi[s], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hlo[s], d, 0, 0, 0);
+        }
+        const f32x4h bv = *reinterpret_cast<const f32x4h *>(b1 + jt * 16 + 4 * q);
+        const f32x4h wv = *reinterpret_cast<const f32x4h *>(w2 + jt * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; j++) z += fmaxf(d[j] + bv[j], 0.f) * wv[j];
+    }
+    z += __shfl_xor(z, 16);
+    z += __shfl_xor(z, 32);
+    if (valid && q == 0) value[board] = tanhf(z + w2[256]);    // b2 from memory: weights may change under a captured graph
+}
+
+__global__ __launch_bounds__(64) void k_value_head(const float *__restrict__ act, int n_boards,
+                                                   const unsigned char *__restrict__ w1p,
+                                                   const float *__restrict__ b1, const float *__restrict__ w2,
+                                                   float *__restrict__ value)
+{
+    value_head_block(act, n_boards, blockIdx.x, w1p, b1, w2, value, threadIdx.x);
+}
+
 // ---- policy head: softmax(h[128] . W[128][1968] + b) -> policy[n][1968] ---------------------------
 // One 512-thread workgroup per 16 NBLK boards; wave w owns labels [256 w, 256 w + 256) (16 tiles) of
 // all its boards.  Every workgroup streams the whole packed kernel (1 MiB) from L2, which is what
@@ -72,11 +118,23 @@ __global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict_
                                                         const float *__restrict__ bias,          // [2048], pad = -1e30
                                                         float *__restrict__ policy,              // LEGAL: priors[n][256]
                                                         const unsigned short *__restrict__ labels = nullptr,
-                                                        const int *__restrict__ counts = nullptr)
+                                                        const int *__restrict__ counts = nullptr,
+                                                        int pol_blocks = 0x7FFFFFFF,             // workgroups beyond: the value head
+                                                        const unsigned char *__restrict__ w1p = nullptr,
+                                                        const float *__restrict__ b1 = nullptr,
+                                                        const float *__restrict__ w2 = nullptr,
+                                                        float *__restrict__ value = nullptr)
 {
     static_assert(!LEGAL || NBLK == 1, "the legal-move gather handles one 16-board block");
     __shared__ float s_max[NBLK][8][16], s_sum[NBLK][8][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= pol_blocks) {
+        // the VALUE head rides in the same launch: workgroup pol_blocks + k serves board blocks 8 k .. 8 k + 7,
+        // one wave each (k_value_head's arithmetic; no workgroup barrier on this path)
+        const int vblock = ((int)blockIdx.x - pol_blocks) * 8 + wave;
+        if (vblock * 16 < n_boards) value_head_block(act, n_boards, vblock, w1p, b1, w2, value, lane);
+        return;
+    }
     const int r = lane & 15, q = lane >> 4;
     int board[NBLK];
     bool valid[NBLK];
@@ -208,43 +266,6 @@ __global__ __launch_bounds__(512, 2) void k_policy_head(const float *__restrict_
     }
 }
 
-// ---- value head: tanh(relu(h[64] . W1[64][256] + b1) . W2[256] + b2) -> value[n] -------------------
-// One wavefront per 16 boards.
-__global__ __launch_bounds__(64) void k_value_head(const float *__restrict__ act, int n_boards,
-                                                   const unsigned char *__restrict__ w1p,    // packed fp16
-                                                   const float *__restrict__ b1,
-                                                   const float *__restrict__ w2,             // [257]: w2, then b2
-                                                   float *__restrict__ value)
-{
-    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
-    const int board = blockIdx.x * 16 + r;
-    const bool valid = board < n_boards;
-    const float *row = act + (size_t)board * ACT + 128;
-    half8 hhi[2], hlo[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
-    const half8 *wf = reinterpret_cast<const half8 *>(w1p) + lane;
-    float z = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < 16; jt++) {
-        f32x4h d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const half8 ahi = wf[((jt * 2 + s) * 2 + 0) * 64], alo = wf[((jt * 2 + s) * 2 + 1) * 64];
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hhi[s], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, hhi[s], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hlo[s], d, 0, 0, 0);
-        }
-        const f32x4h bv = *reinterpret_cast<const f32x4h *>(b1 + jt * 16 + 4 * q);
-        const f32x4h wv = *reinterpret_cast<const f32x4h *>(w2 + jt * 16 + 4 * q);
-#pragma unroll
-        for (int j = 0; j < 4; j++) z += fmaxf(d[j] + bv[j], 0.f) * wv[j];
-    }
-    z += __shfl_xor(z, 16);
-    z += __shfl_xor(z, 32);
-    if (valid && q == 0) value[board] = tanhf(z + w2[256]);    // b2 from memory: weights may change under a captured graph
-}
-
 // ---- the same two heads for SMALL batches: label slices x board blocks ------------------------------
 // k_policy_head gives every workgroup 16 boards and ALL 2048 labels: a batch of 512 boards is 32
 // workgroups, each pulling the whole 1-MiB packed kernel through one CU (14 us: a fifth of a C2
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(64) void k_value_head(const float *__restrict__ act
 //     M = max_k m_k,   S = sum_k s_k exp(m_k - M)   (k = 0..7 in that order: reproducible).
 // FULL and LEGAL run the same arithmetic on the same numbers: identical values, as in the one-pass
 // kernel.  The values differ from the one-pass kernel's in the last bits (another summation order).
-constexpr int N_SLICES = 8;
+constexpr int N_SLICES = crl_slices::N_SLICES;
 constexpr int SLICE_LABELS = N_LABELS_PAD / N_SLICES;     // 256
 constexpr int SL_STRIDE = SLICE_LABELS + 4;               // LDS row of a board's slice logits
 
@@ -284,30 +305,7 @@ __global__ __launch_bounds__(256) void k_heads_sliced(const float *__restrict__ 
     if (slice == N_SLICES) {
         // ---- value head of this board block: tanh(relu(h . W1 + b1) . W2 + b2), one wave
         if (wave != 0 || !value) return;
-        const float *row = act + (size_t)board * ACT + 128;
-        half8 hhi[2], hlo[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++) split_act(row, valid, 32 * s + 8 * q, hhi[s], hlo[s]);
-        const half8 *wf = reinterpret_cast<const half8 *>(w1p) + lane;
-        float z = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 16; jt++) {
-            f32x4h d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const half8 ahi = wf[((jt * 2 + s) * 2 + 0) * 64], alo = wf[((jt * 2 + s) * 2 + 1) * 64];
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hhi[s], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, hhi[s], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, hlo[s], d, 0, 0, 0);
-            }
-            const f32x4h bv = *reinterpret_cast<const f32x4h *>(b1 + jt * 16 + 4 * q);
-            const f32x4h wv = *reinterpret_cast<const f32x4h *>(w2 + jt * 16 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; j++) z += fmaxf(d[j] + bv[j], 0.f) * wv[j];
-        }
-        z += __shfl_xor(z, 16);
-        z += __shfl_xor(z, 32);
-        if (valid && q == 0) value[board] = tanhf(z + w2[256]);
+        value_head_block(act, n_boards, blockIdx.y, w1p, b1, w2, value, lane);
         return;
     }
     // ---- policy logits of labels [256 slice + 64 wave, +64) for the 16 boards
@@ -389,27 +387,18 @@ __global__ __launch_bounds__(256) void k_policy_normalise(float *__restrict__ po
 {
     const int lane = threadIdx.x & 63, board = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (board >= n_boards) return;
-    float2 st[N_SLICES];
-#pragma unroll
-    for (int k = 0; k < N_SLICES; k++) st[k] = stats[(size_t)board * N_SLICES + k];
-    float M = st[0].x;
-#pragma unroll
-    for (int k = 1; k < N_SLICES; k++) M = fmaxf(M, st[k].x);
-    float S = 0.f;
-#pragma unroll
-    for (int k = 0; k < N_SLICES; k++) S += st[k].y * __expf(st[k].x - M);
-    const float inv = 1.0f / S;
+    const crl_slices::Norm nm = crl_slices::norm_of(stats + (size_t)board * N_SLICES);
     if constexpr (LEGAL) {
         int cnt = counts[board];
         cnt = cnt < 0 ? 0 : (cnt > LEGAL_STRIDE ? LEGAL_STRIDE : cnt);
         float *row = policy + (size_t)board * LEGAL_STRIDE;
-        for (int j = lane; j < cnt; j += 64) row[j] = __expf(row[j] - M) * inv;
+        for (int j = lane; j < cnt; j += 64) row[j] = crl_slices::prob(row[j], nm);
     } else {
         f32x4h *row = reinterpret_cast<f32x4h *>(policy + (size_t)board * N_LABELS);     // 1968 floats = 492 quads, 16-byte aligned
         for (int j = lane; j < N_LABELS / 4; j += 64) {
             f32x4h v = row[j];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = __expf(v[e] - M) * inv;
+            for (int e = 0; e < 4; e++) v[e] = crl_slices::prob(v[e], nm);
             row[j] = v;
         }
     }

@@ -24,6 +24,7 @@
 //   one that created it visits exactly one of its children.
 #pragma once
 #include "movegen.hpp"
+#include "slices.hpp"
 #include "state.hpp"
 
 namespace crl {
@@ -195,12 +196,23 @@ __device__ inline void init_edges(const Dev &d, size_t eb, int edge0, int n, con
     }
 }
 
-// legal = false: pol is a full policy[row][1968], gathered at the labels of the node's moves;
-// legal = true: pol is priors[row][MAX_MOVES], entry j for the node's legal move j (the evaluator
-// gathered them from the label list the search kernel that created the position wrote)
+// fmt = CRL_POLICY_FULL: pol is a full policy[row][1968], gathered at the labels of the node's moves;
+// fmt = CRL_POLICY_LEGAL: pol is priors[row][MAX_MOVES], entry j for the node's legal move j (the evaluator
+// gathered them from the label list the search kernel that created the position wrote);
+// fmt = CRL_POLICY_LEGAL_RAW: the same rows holding LOGITS; `stats` are the board's slice statistics and
+// the probability is formed here (csrc/slices.hpp: the arithmetic of the normalising pass, same bits)
+constexpr int FMT_FULL = 0, FMT_LEGAL = 1, FMT_LEGAL_RAW = 2;
+
 __device__ inline void gather_priors(const Dev &d, int row, size_t eb, int edge0, int n,
-                                     const float *pol, int lane, bool legal)
+                                     const float *pol, int lane, int fmt, const float2 *stats = nullptr)
 {
+    if (fmt == FMT_LEGAL_RAW) {
+        const crl_slices::Norm nm = crl_slices::norm_of(stats + (size_t)row * crl_slices::N_SLICES);
+        for (int j = lane; j < n; j += 64)
+            d.edge[eb + edge0 + j].prior = crl_slices::prob(pol[(size_t)row * MAX_MOVES + j], nm);
+        return;
+    }
+    const bool legal = fmt == FMT_LEGAL;
     for (int j = lane; j < n; j += 64) {
         size_t e = eb + edge0 + j;
         if (legal) {
@@ -226,15 +238,21 @@ __device__ inline void write_labels(const Dev &d, int row, const u16 *mv, int n,
 
 // index of the first maximum of policy[label(m)] over the n moves in mv (np.argmax)
 __device__ inline int argmax_policy(const Dev &d, int row, const u16 *mv, int n, const float *pol,
-                                    int lane, bool legal)
+                                    int lane, int fmt, const float2 *stats = nullptr)
 {
     float best = -__builtin_inff();
     int bi = 0x7FFFFFFF;
+    crl_slices::Norm nm = {0.f, 0.f};
+    if (fmt == FMT_LEGAL_RAW) nm = crl_slices::norm_of(stats + (size_t)row * crl_slices::N_SLICES);
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         if (i < n) {
             float p;
-            if (legal) {
+            if (fmt == FMT_LEGAL_RAW) {
+                // the argmax runs over the PROBABILITIES the normalising pass would have stored (two
+                // logits may round to one probability; np.argmax then takes the first)
+                p = crl_slices::prob(pol[(size_t)row * MAX_MOVES + i], nm);
+            } else if (fmt == FMT_LEGAL) {
                 p = pol[(size_t)row * MAX_MOVES + i];
             } else {
                 int lab = label_of(d, mv[i]);
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(64) void k_greedy(Dev d, const float *pol, const ui
     MoveGenInfo mi = wave_movegen(b, lane, s.mv);
     __syncthreads();
     if (mi.n == 0) return;                    // legal[argmax([])] would raise; game is over
-    const int bi = argmax_policy(d, r, s.mv, mi.n, pol, lane, false);    // always a full policy
+    const int bi = argmax_policy(d, r, s.mv, mi.n, pol, lane, FMT_FULL);    // always a full policy
     const u32 mv = s.mv[bi];
     __syncthreads();
     if (lane == 0) moves_out[r] = (u16)mv;
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(64) void k_root_priors(Dev d, const float *pol)
     const int r = blockIdx.x, g = r + d.g0, lane = threadIdx.x;
     if (d.game[g].root_dead) return;
     NodeMeta m = d.node[(size_t)g * d.N].meta;
-    gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane, false);   // the root's policy is always full
+    gather_priors(d, r, (size_t)g * d.ECAP, m.edge0, m.nmoves, pol, lane, FMT_FULL);   // the root's policy is always full
     if (lane == 0) d.counters[(size_t)g * CNT_N + CNT_EVALS] += 1;
 }
 
@@ -496,7 +514,7 @@ __device__ inline void backup_pending(const Dev &d, int g, int row, int lane, co
         v = (double)m.result;                          // state.get_result() (mctree.py:268)
     } else {
         v = (double)val2[row];                           // python float of the f32 value head
-        gather_priors(d, row, eb, m.edge0, m.nmoves, pol2, lane, d.policy_fmt != 0);
+        gather_priors(d, row, eb, m.edge0, m.nmoves, pol2, lane, d.policy_fmt, d.stats_s2);
         evals = 1;                                     // policy/value(S2)
     }
     if (kind == LEAF_NEW_S2) evals += 1;               // policy(S1) chose the reply
@@ -666,7 +684,7 @@ __global__ __launch_bounds__(64) void k_reply(Dev d, const float *pol1, void *pl
     Board s1 = d.node[nb + c].s1;
     // agent.best_move(S1, real_game=True): legal[argmax(policy masked to legal)]
     const u16 *mv1 = d.s1_moves + (size_t)g * MAX_MOVES;
-    const int bi = argmax_policy(d, r, mv1, n1, pol1, lane, d.policy_fmt != 0);
+    const int bi = argmax_policy(d, r, mv1, n1, pol1, lane, d.policy_fmt, d.stats_s1);
     const u32 reply = mv1[bi];
     Board s2 = apply_move(s1, reply);
     PosEval e = eval_position(d, g, s2, 2 * level, p, p, lane, s);

@@ -98,7 +98,10 @@ struct Dev {
     u32 flags;
     int plane_fmt;                     // 0: encoders write fp16 NHWC planes, 1: 128 bit planes per position
     int policy_fmt;                    // 0: evaluators hand back policy[row][1968]; 1: priors[row][256] of the
-                                       //    legal moves the search kernels listed in lab_s1 / lab_s2
+                                       //    legal moves the search kernels listed in lab_s1 / lab_s2; 2: the same
+                                       //    rows holding LOGITS, to be normalised on read with the slice
+                                       //    statistics in stats_s1 / stats_s2 (csrc/slices.hpp)
+    const float2 *stats_s1, *stats_s2; // [rows][8] (max, sum exp) per label slice, window-relative rows
     // games
     GameRow *game;
     Board *cur;

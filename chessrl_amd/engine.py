@@ -118,7 +118,7 @@ class LockstepEngine(object):
     """
 
     def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
-                 numpy_promotion="auto", use_graph=True, bitplanes=None, legal_priors=None):
+                 numpy_promotion="auto", use_graph=True, bitplanes=None, legal_priors=None, raw_priors=None):
         numpy_promotion = resolve_numpy_promotion(numpy_promotion)
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
@@ -154,12 +154,21 @@ class LockstepEngine(object):
             legal_priors = bool(getattr(evaluator, "accepts_legal_labels", False))
         self.legal_priors = legal_priors
         self.pri_s1 = self.pri_s2 = None
+        self.raw_priors = False
+        self._want_raw = raw_priors              # None: wherever the heads support it; False: never
         if legal_priors:
-            self.ctx.set_policy_format(True)
             self.pri_s1 = torch.zeros((G, _lib.MAX_MOVES), dtype=torch.float32, device=self.dev)
             self.pri_s2 = torch.zeros((G, _lib.MAX_MOVES), dtype=torch.float32, device=self.dev)
             self._lab_s1 = self.ctx.eval_labels(0)
             self._lab_s2 = self.ctx.eval_labels(1)
+            # small batches: the heads leave logits + the softmax statistics of their label slices and
+            # the search kernels normalise on read (CRL_POLICY_LEGAL_RAW): one launch fewer per tower
+            # call.  Each evaluation slot owns its statistics (S2's are read by the NEXT step's select).
+            self.stats_s1 = torch.zeros((G, 16), dtype=torch.float32, device=self.dev)
+            self.stats_s2 = torch.zeros((G, 16), dtype=torch.float32, device=self.dev)
+            self.ctx.set_policy_stats(0, self.stats_s1.data_ptr())
+            self.ctx.set_policy_stats(1, self.stats_s2.data_ptr())
+            self._pick_policy_format()
         else:
             self.pri_s1, self.pri_s2 = self.pol_s1, self.pol_s2
         self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
@@ -169,6 +178,14 @@ class LockstepEngine(object):
         self._bind_stream()
 
     # ---- plumbing ---------------------------------------------------------------------
+    def _pick_policy_format(self):
+        """CRL_POLICY_LEGAL_RAW where the evaluator's heads can skip their normalising pass for this
+        batch size, else CRL_POLICY_LEGAL.  Only called while no simulation is pending (construction,
+        ``shrink`` at a move boundary): priors written in one format are never read in the other."""
+        sup = getattr(self.evaluator, "raw_priors_supported", None)
+        self.raw_priors = bool(self._want_raw is not False and sup is not None and sup(self.G))
+        self.ctx.set_policy_format(_lib.POLICY_LEGAL_RAW if self.raw_priors else _lib.POLICY_LEGAL)
+
     def _bind_stream(self):
         self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
 
@@ -186,6 +203,8 @@ class LockstepEngine(object):
         self.G = n
         (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
          self.pri_s1, self.pri_s2) = (t[:n] for t in self._full)
+        if self.legal_priors:
+            self._pick_policy_format()
         self._graph = None
 
     def _eval_into(self, planes, pol_out, val_out):
@@ -204,7 +223,8 @@ class LockstepEngine(object):
 
     def phase_tower_s1(self):
         if self.legal_priors:
-            self.evaluator.forward_legal_into(self.planes_s1, self._lab_s1[0], self._lab_s1[1], self.pri_s1, None)
+            self.evaluator.forward_legal_into(self.planes_s1, self._lab_s1[0], self._lab_s1[1], self.pri_s1, None,
+                                              **({"stats_out": self.stats_s1} if self.raw_priors else {}))
         else:
             self._eval_into(self.planes_s1, self.pol_s1, None)
 
@@ -213,7 +233,8 @@ class LockstepEngine(object):
 
     def phase_tower_s2(self):
         if self.legal_priors:
-            self.evaluator.forward_legal_into(self.planes_s2, self._lab_s2[0], self._lab_s2[1], self.pri_s2, self.val_s2)
+            self.evaluator.forward_legal_into(self.planes_s2, self._lab_s2[0], self._lab_s2[1], self.pri_s2, self.val_s2,
+                                              **({"stats_out": self.stats_s2} if self.raw_priors else {}))
         else:
             self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
 

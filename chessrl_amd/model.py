@@ -393,10 +393,15 @@ class ChessModel(object):
                  if want_trunk else None)
         heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
         split = (precision or self.precision) == "f16x3"
+        image = self._wtiles3 if split else self._wtiles
+        if image.numel() <= 8:                   # the placeholder: this mode's weight image was never packed
+            raise _lib.HipLibraryError("the weight image of precision mode %r is not packed (model built with "
+                                       "precision=%r): use set_precision() or precision='auto'"
+                                       % ("f16x3" if split else "f16", self.precision_requested))
         flags = (_lib.TRUNK_BITPLANES if bits else 0) | (_lib.TRUNK_SPLIT if split else 0)
         rc = _lib.lib().crl_trunk_forward_x(
             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters, flags,
-            ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p((self._wtiles3 if split else self._wtiles).data_ptr()),
+            ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(image.data_ptr()),
             ctypes.c_void_p(self._wbias.data_ptr()),
             ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
             ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
@@ -487,24 +492,36 @@ class ChessModel(object):
         return bool(self.fused)
 
     @torch.no_grad()
-    def forward_legal_into(self, planes, labels_ptr, counts_ptr, priors_out, val_out):
+    def forward_legal_into(self, planes, labels_ptr, counts_ptr, priors_out, val_out, stats_out=None):
         """Evaluate and write, per board, the policy at the labels listed in the device arrays
         ``labels_ptr`` (uint16 [B,256]) / ``counts_ptr`` (int32 [B]) into ``priors_out`` (fp32
-        [B,256]) and the value into ``val_out`` (fp32 [B], or None: S1 evaluations need no value)."""
+        [B,256]) and the value into ``val_out`` (fp32 [B], or None: S1 evaluations need no value).
+        With ``stats_out`` (fp32 [B,16]; only for batches ``raw_priors_supported``) the rows receive
+        the LOGITS and ``stats_out`` the softmax statistics of the label slices: the search kernels
+        normalise on read (CRL_POLICY_LEGAL_RAW) and the heads' normalising pass is not launched."""
         import ctypes
         from . import _lib
         if not self.fused:
             raise _lib.HipLibraryError("forward_legal_into needs the fused HIP tower")
         _, hp = self._run_fused(planes)
         vp = ctypes.c_void_p
-        rc = _lib.lib().crl_heads_forward_legal(
+        fn = _lib.lib().crl_heads_forward_legal if stats_out is None else _lib.lib().crl_heads_forward_legal_raw
+        scratch = self._heads_scratch(hp.shape[0]) if stats_out is None else stats_out
+        rc = fn(
             vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), hp.shape[0],
             vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
             vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr), vp(counts_ptr),
             vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None),
-            vp(self._heads_scratch(hp.shape[0]).data_ptr()))
+            vp(scratch.data_ptr()))
         if rc != 0:
-            raise _lib.HipLibraryError("crl_heads_forward_legal failed (%d)" % rc)
+            raise _lib.HipLibraryError("%s failed (%d)" % ("crl_heads_forward_legal" if stats_out is None
+                                                           else "crl_heads_forward_legal_raw", rc))
+
+    def raw_priors_supported(self, n_boards):
+        """Whether a batch of ``n_boards`` is served by the sliced heads, i.e. may leave the softmax
+        normalisation to the search kernels (``forward_legal_into(..., stats_out=...)``)."""
+        from . import _lib
+        return bool(self.fused and _lib.lib().crl_heads_raw_supported(int(n_boards)))
 
     @torch.no_grad()
     def forward_into(self, planes, pol_out, val_out):

@@ -63,6 +63,16 @@ typedef enum crl_status {
 
 typedef struct crl_ctx crl_ctx;
 
+/* ---- identity of the library ------------------------------------------------------------- */
+/* Bumped whenever a signature or the meaning of an argument below changes.  A binding calls
+ * crl_abi_version() first and refuses a library of another version (a ctypes call through a stale
+ * signature hands the GPU garbage pointers).  crl_source_hash(): sha256 over the sources (csrc/ + this
+ * header + compiler flags) the library was built from, as chessrl_amd/_lib.py computes it; the string
+ * is also findable in the file itself behind the marker "CRL_SRC_HASH=".  No reference counterpart. */
+#define CRL_ABI_VERSION 4
+int  crl_abi_version(void);
+const char *crl_source_hash(void);
+
 /* ---- lifetime ------------------------------------------------------------------- */
 int  crl_create(crl_ctx **out, int device, int max_games, int max_sims, int max_plies,
                 uint32_t flags);
@@ -92,10 +102,18 @@ int  crl_set_plane_format(crl_ctx *ctx, int format);
  * crl_sim_select_expand (S1), crl_eval_labels(ctx, 1, ...) after crl_sim_reply (S2): device pointers
  * to uint16 [count][CRL_MAX_MOVES] and int32 [count] (0 = this row needs no policy in this step),
  * rows window-relative, valid for the life of the context.  crl_heads_forward_legal consumes them.
- * crl_search_root_priors and crl_greedy_moves always take full policies. */
+ * crl_search_root_priors and crl_greedy_moves always take full policies.
+ * CRL_POLICY_LEGAL_RAW = rows as CRL_POLICY_LEGAL, but holding the LOGITS of the legal moves, with the
+ * softmax statistics of the board (8 label slices x (max, sum exp), float [rows][16]) at the address given
+ * to crl_set_policy_stats(ctx, which, ...) (which = 0: the evaluation of S1, read by crl_sim_reply; 1: of
+ * S2, read by crl_sim_select_expand / crl_sim_backup): the kernels form exp(l - M) / S on read -- the
+ * arithmetic of the heads' normalising pass, same bits -- so small batches need no such pass
+ * (crl_heads_forward_legal_raw).  Both addresses must be set before the format is selected. */
 #define CRL_POLICY_FULL  0
 #define CRL_POLICY_LEGAL 1
+#define CRL_POLICY_LEGAL_RAW 2
 int  crl_set_policy_format(crl_ctx *ctx, int format);
+int  crl_set_policy_stats(crl_ctx *ctx, int which, const void *dev_stats_f32);
 int  crl_eval_labels(crl_ctx *ctx, int which, const uint16_t **dev_labels, const int32_t **dev_counts);
 int  crl_max_games(crl_ctx *ctx);
 int  crl_max_sims(crl_ctx *ctx);
@@ -182,28 +200,21 @@ int  crl_counters(crl_ctx *ctx, uint64_t *out6);
 
 /* ---- tower seam (model.py) -------------------------------------------------------------- */
 /* Residual trunk of ChessModel (model.py:33-37,111-122: stem conv + n_blocks residual blocks,
- * BatchNorm folded) for 128 filters as ONE fused MFMA kernel, plus the three 1x1 head
+ * BatchNorm folded) for `filters` in {64, 128, 256} (BASELINE configs C2, C3/C4, C5; 256 is the
+ * reference's own width, model.py:33) as ONE fused MFMA kernel, plus the three 1x1 head
  * convolutions with their BN + ReLU (model.py:40-42,51-55).  fp16 NHWC planes
  * [n_boards][8][8][128] in.  dev_wtiles_f16 holds the folded fp16 kernels as 64-byte-row planes in
- * consumption order [conv][tap = ky*3+kx][in-ch/32][128 rows][4 chunks][8 in] -- byte for byte the
- * image the kernel keeps in LDS, so that its weight DMA copies contiguous 16-KiB blocks: row r of a
+ * consumption order [conv][tap = ky*3+kx][in-ch/32][filters rows][4 chunks][8 in] -- byte for byte the
+ * image the kernel keeps in LDS, so that its weight DMA copies contiguous blocks: row r of a
  * plane holds output channel (r & ~31) + 8*((r & 15) >> 2) + 4*((r >> 4) & 1) + (r & 3), and the
  * 16-byte chunk with input channels 8c .. 8c+7 of that row sits at position c ^ ((-(r >> 2)) & 3)
- * (chessrl_amd/model.py:_pack_fused is the reference packer); dev_bias_f32 is [1+2*n_blocks][128].
- * Outputs (either may be NULL): dev_out_f32 = fp32 trunk activations [n_boards][8][8][128];
+ * (chessrl_amd/model.py:_pack_fused is the reference packer); the stem has 128 input channels, every
+ * other conv `filters`; dev_bias_f32 is [1+2*n_blocks][filters].
+ * Outputs (either may be NULL): dev_out_f32 = fp32 trunk activations [n_boards][8][8][filters];
  * dev_head_out_f32 = [n_boards][192] floats after ReLU: [0,128) the policy head in Keras Flatten
- * order (position*2 + channel), [128,192) the value head; from dev_head_w_f32 [3][128] and
+ * order (position*2 + channel), [128,192) the value head; from dev_head_w_f32 [3][filters] and
  * dev_head_b_f32 [3].  n_boards % 4 == 0.
  * Stateless: needs no crl_ctx. */
-int  crl_trunk128_forward(void *hip_stream, const void *dev_planes_f16, const void *dev_wtiles_f16,
-                          const void *dev_bias_f32, void *dev_out_f32, int n_boards, int n_blocks,
-                          const void *dev_head_w_f32, const void *dev_head_b_f32,
-                          void *dev_head_out_f32);
-/* The same for `filters` in {64, 128, 256} (BASELINE configs C2, C3/C4, C5; 256 is the
- * reference's own width, model.py:33).  The weight image is the same sequence of planes
- * [conv][tap][in-ch/32][filters rows][4 chunks][8 in] with the row and chunk order given above
- * (the row rule repeats every 32 rows); the stem has 128 input channels, every other conv `filters`.  Biases [1+2*n_blocks][filters], head weights [3][filters], trunk output
- * [n_boards][8][8][filters]. */
 int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
                        const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                        int n_boards, int n_blocks, const void *dev_head_w_f32,
@@ -260,12 +271,28 @@ int  crl_heads_forward_legal(void *hip_stream, const void *dev_head_act_f32, int
                              const int32_t *dev_counts, void *dev_priors_out_f32, void *dev_value_out_f32,
                              void *dev_scratch_f32);
 
+/* crl_heads_forward_legal without its normalising pass, for batches the sliced form serves
+ * (crl_heads_raw_supported(n_boards) == 1; CRL_ERR_ARG otherwise): dev_logits_out_f32 rows receive the
+ * LOGITS of the legal moves and dev_stats_out_f32 (float [n_boards][16], required) the slice statistics;
+ * the search kernels normalise on read (CRL_POLICY_LEGAL_RAW, crl_set_policy_stats) -- one launch per
+ * tower call instead of two, identical priors. */
+int  crl_heads_forward_legal_raw(void *hip_stream, const void *dev_head_act_f32, int n_boards,
+                                 const void *dev_policy_wp_f16, const void *dev_policy_bias_f32,
+                                 const void *dev_value_w1p_f16, const void *dev_value_b1_f32,
+                                 const void *dev_value_w2b2_f32, const uint16_t *dev_labels,
+                                 const int32_t *dev_counts, void *dev_logits_out_f32, void *dev_value_out_f32,
+                                 void *dev_stats_out_f32);
+int  crl_heads_raw_supported(int n_boards);
+
 /* dev_scratch_f32 of the two calls above: float [n_boards][16] or NULL.  With it, batches of at most
  * crl_heads_set_sliced_max boards (default 2048: measured 16 vs 17 us there, 9 vs 17 us at 512) run as label slices x board blocks (8 slices of 256
  * labels, the value head as a ninth "slice": 9 x n_boards/16 workgroups instead of n_boards/16)
  * followed by a normalising pass that reads the slice statistics left in the scratch -- a batch of
  * 512 boards otherwise pulls the whole 1-MiB policy kernel through each of 32 CUs.  Same results for
- * the two calls (bit for bit); the last bits differ from the one-pass form (summation order). */
+ * the two calls (bit for bit); the last bits differ from the one-pass form (summation order).  Larger batches run ONE launch: the
+ * policy head's workgroups and, behind them, the value head's.
+ * PROCESS-GLOBAL tuning state (like crl_trunk_set_small_batch below): it applies to every context and
+ * stream of the process; meant to be set once at start-up, not per context. */
 int  crl_heads_set_sliced_max(int boards);
 
 /* Batches of at most 512 boards (256 at 256 filters) give at most half of the 256 CUs a

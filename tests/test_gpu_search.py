@@ -516,16 +516,18 @@ def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards,
 @pytest.mark.parametrize("sims,graph", [(40, False), (130, True)])
 def test_search_with_legal_priors_is_identical_to_search_with_full_policies(sims, graph):
     """CRL_POLICY_LEGAL (the heads write only the legal moves' probabilities, the search kernels
-    publish the label lists) against CRL_POLICY_FULL on the same games: same trees, bit for bit,
-    through replies, terminal children, finished roots, and a second move after advance."""
+    publish the label lists) and CRL_POLICY_LEGAL_RAW (the heads leave logits + slice statistics and
+    the search kernels normalise on read: no normalising pass) against CRL_POLICY_FULL on the same
+    games: same trees, bit for bit, through replies, terminal children, finished roots, and a second
+    move after advance."""
     from chessrl_amd.engine import LockstepEngine
     from chessrl_amd.model import ChessModel
     model = ChessModel(blocks=2, filters=64, seed=3)
     games = random_prefix_games(24, 70, seed=29)
     out = []
-    for legal in (False, True):
-        eng = LockstepEngine(model, n_games=24, max_sims=sims, legal_priors=legal, use_graph=graph)
-        assert eng.legal_priors == legal
+    for legal, raw in ((False, False), (True, False), (True, None)):
+        eng = LockstepEngine(model, n_games=24, max_sims=sims, legal_priors=legal, use_graph=graph, raw_priors=raw)
+        assert eng.legal_priors == legal and eng.raw_priors == (raw is None)
         eng.load_moves([move_ids(g) for g in games])
         eng.search(sims)
         first = eng.root_children()
@@ -534,14 +536,15 @@ def test_search_with_legal_priors_is_identical_to_search_with_full_policies(sims
         eng.search(sims)
         out.append((first, bm, am, eng.root_children(), eng.ctx.counters()))
         eng.close()
-    (a1, abm, aam, a2, ac), (b1, bbm, bam, b2, bc) = out
-    for a, b in ((a1, b1), (a2, b2)):
-        assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
-        assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
-        assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
-        assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
-    assert np.array_equal(abm, bbm) and np.array_equal(aam, bam)
-    assert {k: int(v) for k, v in ac.items()} == {k: int(v) for k, v in bc.items()}
+    (a1, abm, aam, a2, ac) = out[0]
+    for (b1, bbm, bam, b2, bc) in out[1:]:
+        for a, b in ((a1, b1), (a2, b2)):
+            assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
+            assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+            assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
+            assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
+        assert np.array_equal(abm, bbm) and np.array_equal(aam, bam)
+        assert {k: int(v) for k, v in ac.items()} == {k: int(v) for k, v in bc.items()}
     assert LockstepEngine(model, n_games=4, max_sims=2).legal_priors      # the default for the HIP heads
 
 
