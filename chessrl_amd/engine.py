@@ -57,13 +57,15 @@ def dirichlet_row(src, n):
 def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None, noise_rows=None):
     """``np.argmax(compute_policy(...))`` for every game at once (-1 where nchild == 0).
 
-    Same arithmetic as ``compute_policy`` element for element (numpy's array ``power`` and
-    division are the scalar ones applied per element), so the chosen child is identical; only
+    Same arithmetic as ``compute_policy`` element for element (numpy's array ``power``, multiply, add
+    and division are the scalar ones applied per element), so the chosen child is identical; only
     the per-game Dirichlet draw stays a loop because every game owns its random stream.
     ``visits`` [G, >=max(nchild)] int, children order; ``rngs`` one generator per game (or None
     for the global ``np.random`` stream, drawn in game order); ``noise_rows``: the draws already
-    made for this move (``SelfPlayRunner`` makes them while the GPU searches), one row of
-    ``nchild[g]`` entries per game with children.
+    made for this move (``SelfPlayRunner`` makes them while the GPU searches) -- either a list with
+    one row of ``nchild[g]`` entries per game with children, or a pair (matrix float64 [G, >=max
+    nchild] holding the rows left-aligned, counts int [G]): the latter is consumed without a Python
+    loop (4096 per-game argmax calls were most of a move boundary).
     """
     G = len(nchild)
     nchild = np.asarray(nchild)
@@ -76,7 +78,20 @@ def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None, n
                np.power(np.asarray(root_visits, dtype=np.float64), inv_tau)[:, None])
     chosen = np.full(G, -1, dtype=np.int32)
     cols = np.arange(w)
-    if noise:
+    live = nchild > 0
+    if noise and isinstance(noise_rows, tuple):
+        mat, cnt = noise_rows
+        bad = np.nonzero(live & (np.asarray(cnt)[:G] != nchild))[0]
+        if len(bad):
+            g = int(bad[0])
+            raise RuntimeError("noise drawn ahead for %d children, game %d has %d" % (int(cnt[g]), g, int(nchild[g])))
+        if mat.shape[1] < w:
+            raise RuntimeError("noise matrix narrower than the widest root")
+        with np.errstate(invalid="ignore"):
+            noisy = (1 - 0.25) * pol + mat[:G, :w]
+        masked = np.where(cols[None, :] < nchild[:, None], noisy, -np.inf)
+        chosen[live] = np.argmax(masked[live], axis=1)
+    elif noise:
         for g in range(G):
             n = int(nchild[g])
             if n:
@@ -89,7 +104,6 @@ def choose_children(visits, nchild, root_visits, plies, noise=True, rngs=None, n
                     row = dirichlet_row(rngs[g] if rngs is not None else np.random, n)
                 chosen[g] = int(np.argmax((1 - 0.25) * pol[g, :n] + row))
     else:
-        live = nchild > 0
         masked = np.where(cols[None, :] < nchild[:, None], pol, -np.inf)
         chosen[live] = np.argmax(masked[live], axis=1)
     return chosen

@@ -87,6 +87,7 @@ class SelfPlayRunner(object):
         self.sims_run = 0
         self._sims_in_move = None
         self._noise_rows = None                  # this move's Dirichlet draws, made while the GPU searches
+        self._noise_states = {}                  # ... and every drawn stream's state before its draw
         self._root_legal = None                  # len(get_legal_moves()) of every root, read at the boundary
         self._start(np.ones(n_parallel, dtype=bool))
 
@@ -149,11 +150,15 @@ class SelfPlayRunner(object):
         order and with the same arguments as at the boundary: the values are identical."""
         if not self.noise or self._noise_rows is not None or self._root_legal is None:
             return
-        n_final = np.minimum(self._root_legal[:self.G], self.sims)
-        rows = [None] * self.G
-        for g in np.nonzero((self.game_id >= 0) & (n_final > 0))[0]:
-            rows[g] = dirichlet_row(self.rngs[g], int(n_final[g]))
-        self._noise_rows = rows
+        n_final = np.where(self.game_id >= 0, np.minimum(self._root_legal[:self.G], self.sims), 0)
+        mat = np.zeros((self.G, max(1, int(n_final.max()))), dtype=np.float64)
+        # a move that is cut short after this point (end_move before `sims` simulations) ends with fewer
+        # root children and must draw again FROM THE SAME STREAM POSITION: the states are kept until then
+        self._noise_states = {}
+        for g in np.nonzero(n_final > 0)[0]:
+            self._noise_states[g] = self.rngs[g].bit_generator.state
+            mat[g, :n_final[g]] = dirichlet_row(self.rngs[g], int(n_final[g]))
+        self._noise_rows = (mat, n_final)
 
     def end_move(self):
         """Last backprop, compute_policy + argmax on the host, the two pushes, harvest of
@@ -164,6 +169,11 @@ class SelfPlayRunner(object):
         _, plies, _ = eng.ctx.records(with_moves=False)
         nchild = np.where(self.game_id >= 0, rc["nchild"], 0)
         rows = self._noise_rows if self._sims_in_move == self.sims else None    # (a shortened move draws here)
+        if rows is None and self._noise_rows is not None:
+            # shortened AFTER the draw ahead: rewind every stream to where it stood, so that the draw below
+            # is the one the reference would make (one dirichlet per move and game, in stream order)
+            for g, st in self._noise_states.items():
+                self.rngs[g].bit_generator.state = st
         chosen = choose_children(rc["visits"], nchild, rc["root_visits"], plies, noise=self.noise,
                                  rngs=self.rngs, noise_rows=rows)
         self._noise_rows = None

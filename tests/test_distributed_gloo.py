@@ -192,6 +192,20 @@ def test_host_helpers_of_round_3():
     ahead = [dirichlet_row(r, int(k)) if k else None for r, k in zip(mk(), nchild)]
     assert np.array_equal(choose_children(visits, nchild, root, plies, noise=True, rngs=None, noise_rows=ahead),
                           at_boundary)
+    # the padded-matrix form the runner hands over (no per-game Python loop at the boundary)
+    mat = np.zeros((G, 218))
+    for g in range(G):
+        if nchild[g]:
+            mat[g, :nchild[g]] = ahead[g]
+    assert np.array_equal(choose_children(visits, nchild, root, plies, noise=True, noise_rows=(mat, nchild.copy())),
+                          at_boundary)
+    wrong = nchild.copy()
+    wrong[4] = 217
+    try:
+        choose_children(visits, nchild, root, plies, noise=True, noise_rows=(mat, wrong))
+        raise AssertionError("accepted a noise matrix drawn for another child count")
+    except RuntimeError:
+        pass
     ahead[2] = ahead[2][:-1]                                        # a row of the wrong length is refused
     try:
         choose_children(visits, nchild, root, plies, noise=True, noise_rows=ahead)

@@ -302,7 +302,23 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
         off += len(parts) * 9 * cin * F_
 
 
-def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(tmp_path):
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """The gfx950 assembly of the library's device code, compiled with the library's own flags."""
+    import shutil
+    import subprocess
+    from chessrl_amd import _lib
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    asm = str(tmp_path_factory.mktemp("isa") / "api.s")
+    flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.check_call(["hipcc"] + flags + ["-S", "--offload-device-only",
+                                               os.path.join(ROOT, "chessrl_amd", "csrc", "api.hip"), "-o", asm],
+                          stderr=subprocess.DEVNULL)
+    return asm
+
+
+def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(device_asm):
     """The trunk kernels issue their fragment reads as inline-asm ``ds_read_b128`` with hand-counted
     ``s_waitcnt lgkmcnt`` (hipcc would otherwise undo the software pipeline), so hipcc does not know
     that those registers are not valid yet and may copy them -- phi moves at a loop back-edge -- before
@@ -310,22 +326,88 @@ def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(tmp_path
     split-precision kernels differed from run to run once a second process shared the GPU).
     tools/check_asm_hazards.py walks the ISA of every k_trunk_x16 kernel the library contains and
     reports any instruction reading a register whose ds_read is still in flight."""
-    import shutil
     import subprocess
     import sys
-    from chessrl_amd import _lib
-    if shutil.which("hipcc") is None:
-        pytest.skip("hipcc not available")
-    asm = str(tmp_path / "api.s")
-    flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
-    subprocess.check_call(["hipcc"] + flags + ["-S", "--offload-device-only",
-                                               os.path.join(ROOT, "chessrl_amd", "csrc", "api.hip"), "-o", asm],
-                          stderr=subprocess.DEVNULL)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py"), asm],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py"), device_asm],
                        capture_output=True, text=True)
     kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
     assert len(kernels) >= 20, r.stdout                       # every dispatched (F, NB, BITS, PAIR, GROUP, SPLIT)
     assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
+
+
+def _race_checker():
+    import importlib
+    import sys
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    return importlib.import_module("lds_race_check")
+
+
+def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
+    """The other half of the hand-counted pipeline: weight and bias tiles arrive by LDS-DMA
+    (``global_load_lds``) and are retired by counted ``s_waitcnt vmcnt(N)`` + ``s_barrier`` before a ring
+    slot is read, and a slot is refilled only behind a barrier after its last reader.
+    tools/lds_race_check.py EXECUTES all 8 waves of a workgroup of every dispatched trunk kernel (20:
+    F x NB x plane format x PAIR / GROUP x SPLIT) on an emulator of the integer / control subset of the
+    gfx950 ISA -- stem + 2 residual blocks: prologue, steady state, both parities of the layer hand-over,
+    drain -- and checks every LDS byte epoch by epoch: no byte read or written while a DMA transfer into it
+    is in flight, no two transfers into one byte, no byte written by one wave and touched by another without
+    a barrier between, no instruction reading OR overwriting a register with an asm ds_read in flight."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lds_race_check.py"), device_asm, "2"],
+                       capture_output=True, text=True)
+    kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
+    assert len(kernels) >= 20, r.stdout + r.stderr
+    assert r.returncode == 0 and all(": ok " in l for l in kernels), r.stdout
+    for l in kernels:                                        # the emulation really ran the pipeline
+        stats = eval(l.split(": ok ", 1)[1])
+        assert stats["dma_transfers"] > 400 and stats["lds_reads"] > 3000 and stats["epochs"] >= 30, l
+
+
+@pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0", "64,2,1,0,0,0,0", "64,4,1,0,0,1,0", "128,2,1,0,1,0,1"])
+def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
+    """Negative controls of the emulation: loosening a steady-state ``vmcnt`` wait by one, removing a tile
+    barrier and loosening a fragment ``lgkmcnt`` wait by one must each be reported (pair ring, plain ring,
+    group ring and a split-precision kernel)."""
+    chk = _race_checker()
+    seg = dict(chk.kernels_of(device_asm))[kernel]
+
+    def run(lines):
+        ins, labels = chk.parse_kernel(lines)
+        try:
+            return chk.check_workgroup(ins, labels, 1)[0]
+        except chk.EmuError as e:
+            return ["stopped: %s" % e]
+
+    assert run(seg) == []
+    in_asm, vm, lg, bars = False, [], [], []
+    for i, l in enumerate(seg):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        t = l.split(";")[0].strip()
+        if in_asm and t.startswith("s_waitcnt"):
+            (vm if "vmcnt" in t else lg).append(i)
+        if t == "s_barrier":
+            bars.append(i)
+
+    def loosened(i, counter):
+        m = list(seg)
+        n = int(re.search(counter + r"\((\d+)\)", m[i]).group(1))
+        m[i] = m[i].replace("%s(%d)" % (counter, n), "%s(%d)" % (counter, n + 1))
+        return m
+
+    # the hand-counted waits of the loop body (the first ones of each list belong to the prologue)
+    hits = [bool(run(loosened(i, "vmcnt"))) for i in vm[1:4]]
+    assert any(hits), "no loosened vmcnt wait was reported"
+    found = [f for i in lg[3:9] for f in run(loosened(i, "lgkmcnt"))]
+    assert any("asm ds_read in flight" in f for f in found), "no loosened lgkmcnt wait was reported"
+    no_barrier = list(seg)
+    no_barrier[bars[1]] = "\ts_nop 0"
+    assert run(no_barrier), "a removed tile barrier was not reported"
 
 
 def test_dataset_accepts_game_records_and_refuses_unknown_entries():
