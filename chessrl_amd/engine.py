@@ -268,7 +268,9 @@ class LockstepEngine(object):
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: another thread of this process (rank 0's background trainer) may allocate and launch
+        # on its own stream while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._bind_stream()              # kernels must land on the capturing stream
             self._step_body()
         self._bind_stream()

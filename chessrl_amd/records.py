@@ -16,17 +16,23 @@ import numpy as np
 from .game import move_to_uci, uci_to_move
 
 HEADER = 5      # game_id_lo, game_id_hi, plies, result, player_color
+RESULT_NONE_WIRE = 2        # result None on the wire (the game was still running: Game.get_result(), game.py:92-109)
+RESULT_TRUNCATED_WIRE = 3   # result None because the record reached max_plies and the runner ended the game
 
 
 class GameRecord(object):
-    __slots__ = ("game_id", "moves", "result", "player_color", "date")
+    __slots__ = ("game_id", "moves", "result", "player_color", "date", "truncated")
 
-    def __init__(self, game_id, moves, result, player_color, date=None):
+    def __init__(self, game_id, moves, result, player_color, date=None, truncated=False):
         self.game_id = int(game_id)
         self.moves = np.asarray(moves, dtype=np.uint16)
         self.result = None if result is None else int(result)
         self.player_color = bool(player_color)
         self.date = date
+        # the game did not end by the rules: its record filled the engine's max_plies and the runner handed
+        # it over as it stood (result None, as Game.get_result() says of a running game).  Not part of
+        # get_history(): the reference's record has no such key.
+        self.truncated = bool(truncated)
 
     def get_history(self):
         return {"moves": [move_to_uci(m) for m in self.moves], "result": self.result,
@@ -87,7 +93,8 @@ def pack(records, max_plies):
             raise ValueError("record longer than max_plies")
         moves[i, :len(r.moves)] = r.moves
     return pack_arrays([r.game_id for r in records], moves, [len(r.moves) for r in records],
-                       [2 if r.result is None else r.result for r in records],
+                       [(RESULT_TRUNCATED_WIRE if r.truncated else RESULT_NONE_WIRE) if r.result is None else r.result
+                        for r in records],
                        [int(r.player_color) for r in records], max_plies)
 
 
@@ -95,15 +102,17 @@ def unpack(rows):
     rows = np.ascontiguousarray(rows, dtype=np.int32)
     mv = rows[:, HEADER:].copy().view(np.uint16) if len(rows) else np.zeros((0, 0), np.uint16)
     gid = rows[:, 0].astype(np.int64) | (rows[:, 1].astype(np.int64) << 31)
-    return [GameRecord(int(gid[i]), mv[i, :int(rows[i, 2])], None if rows[i, 3] == 2 else int(rows[i, 3]),
-                       bool(rows[i, 4])) for i in range(len(rows))]
+    return [GameRecord(int(gid[i]), mv[i, :int(rows[i, 2])],
+                       None if rows[i, 3] in (RESULT_NONE_WIRE, RESULT_TRUNCATED_WIRE) else int(rows[i, 3]),
+                       bool(rows[i, 4]), truncated=bool(rows[i, 3] == RESULT_TRUNCATED_WIRE)) for i in range(len(rows))]
 
 
 def gather_blocks(block, device=None, stats=None, force_collective=False):
     """Every rank's wire block on every rank: (rows of all ranks concatenated in rank order,
-    per-rank row counts).  Two collectives -- the counts, then the blocks padded to the largest
-    count -- and ONE device-to-host copy each; RCCL over xGMI with the ``nccl`` backend, ``gloo``
-    in the CPU tests.  ``stats`` (a dict) receives the bytes moved and the wall time of the
+    per-rank row counts).  Two collectives -- (count, longest record) of every rank, then the blocks
+    padded to the largest count and TRIMMED to the longest record of any rank (a block is packed
+    for max_plies, 4.1 KB per row at 2048, while a game is ~320 plies: 0.65 KB) -- and ONE
+    device-to-host copy each; RCCL over xGMI with the ``nccl`` backend, ``gloo`` in the CPU tests.  ``stats`` (a dict) receives the bytes moved and the wall time of the
     exchange (host staging included).  A world of one returns the block as it is unless
     ``force_collective`` (self-test of the RCCL path on a 1-GPU box: communicator, both
     all_gathers and the device-to-host copies run on a single rank)."""
@@ -121,12 +130,15 @@ def gather_blocks(block, device=None, stats=None, force_collective=False):
     dev = device if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
     t0 = time.perf_counter()
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, torch.tensor([block.shape[0]], dtype=torch.int64, device=dev))
-    counts = [int(c) for c in counts.cpu().tolist()]
-    nmax, w = max(counts), block.shape[1]
+    need = HEADER + (int(block[:, 2].max()) + 1) // 2 if block.shape[0] else HEADER
+    mine = torch.tensor([block.shape[0], min(need, block.shape[1])], dtype=torch.int64, device=dev)
+    both = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(both, mine)
+    both = both.cpu().view(world, 2)
+    counts = [int(c) for c in both[:, 0].tolist()]
+    nmax, w = max(counts), int(both[:, 1].max())
     padded = torch.zeros((nmax, w), dtype=torch.int32, device=dev)
-    padded[:block.shape[0]] = torch.from_numpy(block).to(dev)
+    padded[:block.shape[0]] = torch.from_numpy(np.ascontiguousarray(block[:, :w])).to(dev)
     allb = torch.empty((world * nmax, w), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(allb, padded)
     host = allb.cpu().numpy().reshape(world, nmax, w)

@@ -85,6 +85,7 @@ class SelfPlayRunner(object):
         self.finished = []
         self.moves_played = 0
         self.sims_run = 0
+        self.truncated_games = 0                 # records handed over at max_plies (result None)
         self._sims_in_move = None
         self._noise_rows = None                  # this move's Dirichlet draws, made while the GPU searches
         self._noise_states = {}                  # ... and every drawn stream's state before its draw
@@ -177,18 +178,30 @@ class SelfPlayRunner(object):
         chosen = choose_children(rc["visits"], nchild, rc["root_visits"], plies, noise=self.noise,
                                  rngs=self.rngs, noise_rows=rows)
         self._noise_rows = None
+        # A record that cannot take another full move (our move + the reply) has reached the engine's
+        # max_plies: the game is ended HERE and handed over as it stands -- result None, as
+        # Game.get_result() (game.py:92-109) says of a game the rules have not ended, flagged
+        # ``truncated`` -- instead of overflowing the device's record array (a sticky device error that
+        # would end a multi-hour run for one endless game).  Its slot is refilled like any finished one.
+        full = self.active() & (chosen >= 0) & (np.asarray(plies) + 2 > self.max_plies)
+        chosen[full] = -1
         live = int((chosen >= 0).sum())
         eng.advance(chosen)
         self.moves_played += live
         self.sims_run += live * self._sims_in_move
         self._sims_in_move = None
         res = eng.ctx.results()
-        done = (res != _lib.RESULT_NONE) & self.active()
+        done = ((res != _lib.RESULT_NONE) | full) & self.active()
         if done.any():
             moves, plies, res = eng.ctx.records()
             for g in np.nonzero(done)[0]:
-                self.finished.append(GameRecord(self.game_id[g], moves[g, :plies[g]], int(res[g]),
-                                                bool(self.color[g])))
+                ended = res[g] != _lib.RESULT_NONE
+                self.finished.append(GameRecord(self.game_id[g], moves[g, :plies[g]], int(res[g]) if ended else None,
+                                                bool(self.color[g]), truncated=not ended))
+                if not ended:
+                    self.truncated_games += 1
+                    log.warning("game %d reached max_plies=%d after %d plies: handed over unfinished (result None)",
+                                self.game_id[g], self.max_plies, plies[g])
                 if self.round_size:
                     r = int(self.game_id[g]) // self.round_size
                     self._round_done[r] = self._round_done.get(r, 0) + 1
@@ -267,7 +280,10 @@ class SelfPlayRunner(object):
     def rounds_complete(self):
         """Number of leading rounds whose games (this rank's share) have all finished."""
         r = 0
-        while self._round_share(r) > 0 and self._round_done.get(r, 0) >= self._round_share(r):
+        last = None if self.total_games is None else (self.total_games + self.round_size - 1) // self.round_size
+        while (last is None or r < last) and self._round_done.get(r, 0) >= self._round_share(r):
+            if last is None and self._round_share(r) == 0:
+                break
             r += 1
         return r
 
@@ -278,7 +294,7 @@ class SelfPlayRunner(object):
         self.finished = [x for x in self.finished if not lo <= x.game_id < hi]
         return mine
 
-    def run_rolling(self, n_rounds, on_round=None, sync_every=8):
+    def run_rolling(self, n_rounds, on_round=None, sync_every=8, poll=None, on_news=None):
         """The reference's ``play N games, train, repeat`` (selfplay.py:142-163) without its tail: a
         lockstep batch that stops refilling when a round's last game has STARTED runs ever emptier
         until that game ends (game lengths spread 9...788 plies; measured: 28 % of a 4096-game
@@ -289,16 +305,30 @@ class SelfPlayRunner(object):
         asynchronous self-play of AlphaZero instead of the reference's stop-and-train.  With
         ``total_games = n_rounds * round_size`` only the last round has a thinning tail.
 
-        Ranks agree on completed rounds with one scalar all_reduce(MIN) every ``sync_every`` moves
-        (~15 s apart at C3; nothing on the simulation path), so ``on_round`` may use collectives."""
+        Ranks agree on completed rounds with one small all_reduce(MIN) every ``sync_every`` moves
+        (~15 s apart at C3; nothing on the simulation path), so ``on_round`` may use collectives.
+
+        ``poll()`` / ``on_news(k)``: a rank may have news for all ranks that arrives at no particular
+        move -- rank 0's background trainer has finished another weight set.  ``poll()`` returns this
+        rank's monotonic news counter (0 on ranks that never have any); the same all_reduce carries its
+        maximum, and when that rises every rank calls ``on_news(k)`` at the SAME sync index (a
+        collective inside it -- the weight broadcast -- is therefore safe) while nobody waited for it:
+        every rank kept playing until the news was there."""
         if not self.round_size:
             raise ValueError("run_rolling needs round_size")
+        if self.round_size < self.world:
+            raise ValueError("round_size %d is smaller than the number of ranks %d: a rank without a share "
+                             "of a round could never report it complete" % (self.round_size, self.world))
         done, moves = 0, 0
+        self._news_seen = getattr(self, "_news_seen", 0)
         while done < n_rounds:
             if self.active().any():
                 self.play_move()
             moves += 1                               # (a rank whose batch ran dry idles to the next sync)
-            agreed, any_active = self._agree_rounds(moves, sync_every, done)
+            agreed, any_active, news = self._agree_rounds(moves, sync_every, done, poll)
+            if on_news is not None and news > self._news_seen:
+                self._news_seen = news
+                on_news(news)
             while done < min(agreed, n_rounds):
                 recs = self.take_round(done)
                 if on_round is not None:
@@ -306,21 +336,34 @@ class SelfPlayRunner(object):
                 done += 1
             if not any_active and agreed <= done:
                 break                                # nothing is running and no further round is complete
+        if done < min(n_rounds, self.rounds_complete()):
+            raise RuntimeError("run_rolling ended with %d rounds handed over of %d complete" % (done, self.rounds_complete()))
         return done
 
-    def _agree_rounds(self, moves, sync_every, done):
-        """(rounds complete on EVERY rank, is any rank still playing) -- as of the last sync."""
+    def sync_news(self, poll, on_news):
+        """One agreement on the news counter outside the move loop (after the last round: the trainer's
+        remaining weight sets).  Every rank calls it; returns the agreed counter."""
+        _, _, news = self._agree_rounds(0, 1, 0, poll)
+        if on_news is not None and news > getattr(self, "_news_seen", 0):
+            self._news_seen = news
+            on_news(news)
+        return news
+
+    def _agree_rounds(self, moves, sync_every, done, poll=None):
+        """(rounds complete on EVERY rank, is any rank still playing, highest news counter of any rank)
+        -- as of the last sync."""
         local, active = self.rounds_complete(), bool(self.active().any())
+        mine = int(poll()) if poll is not None else 0
         if self.world == 1:
-            return local, active
+            return local, active, mine
         if moves % sync_every:
-            return done, True
+            return done, True, getattr(self, "_news_seen", 0)
         import torch
         import torch.distributed as dist
         dev = self.engine.dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([local, -int(active)], dtype=torch.int64, device=dev)
+        t = torch.tensor([local, -int(active), -mine], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return int(t[0].item()), bool(t[1].item() < 0)
+        return int(t[0].item()), bool(t[1].item() < 0), int(-t[2].item())
 
     def close(self):
         self.engine.close()
@@ -331,7 +374,9 @@ def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=
     ``GameRecord``s (or ``Game``s): anything with ``get_history()``."""
     from .dataset import DatasetGame
     from .netencoder import DataGameSequence
-    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0])
+    # (a record the runner cut off at max_plies has no result to learn a value from: game.py:92-109)
+    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0
+                              and not getattr(r, "truncated", False)])
     if len(data_train) == 0:
         return None
     gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
@@ -339,6 +384,120 @@ def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=
     history = model.train_generator(gen, epochs=epochs, logdir=model_dir)
     model.save_weights(model_path)
     return history
+
+
+def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size=1):
+    """The arithmetic of ``train_model_job`` without a ``ChessModel``: (trained weight dict, history) from
+    a weight dict and the recorded games, on whatever stream is current -- what the background trainer runs
+    beside the self-play that keeps using the model."""
+    from .dataset import DatasetGame
+    from .netencoder import DataGameSequence
+    from .train import Trainer
+    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0
+                              and not getattr(r, "truncated", False)])
+    if len(data_train) == 0:
+        return weights, None
+    gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
+    trainer = Trainer(weights, device)              # a fresh optimizer per round, as in the reference
+    log_fn = None
+    if model_dir is not None:
+        import json
+
+        def log_fn(summary):
+            with open(os.path.join(model_dir, "train_log.jsonl"), "a") as f:
+                f.write(json.dumps(summary) + "\n")
+    history = trainer.fit_generator(gen, epochs=epochs, log=log_fn)
+    return trainer.weights(), history
+
+
+class BackgroundTrainer(object):
+    """Rank 0's trainer on a thread and a HIP stream of its own.
+
+    The reference's loop is play -> train -> play in one process (selfplay.py:142-163).  With rolling
+    rounds on several GPUs a blocking trainer stalls EVERY rank at the weight broadcast (8 x 4096 C3 games
+    are ~416 s of training per ~300 s of play).  Here ``submit(round, records)`` returns at once; the
+    thread trains the rounds in order, each from the weights the previous one produced (a fresh optimizer
+    per round, as every ``train_model_job`` of the reference starts one), writes the weight file, and
+    ``ready()`` -- a monotonic count of finished weight sets -- is what the ranks agree on in their
+    periodic all_reduce (``SelfPlayRunner.run_rolling(poll=..., on_news=...)``).  The inference tensors
+    are only ever rewritten by the main thread at a move boundary (``ChessModel.load_dict``), never here.
+    ``train_fn(weights, records) -> (weights, history)`` defaults to ``train_weights`` on ``device``."""
+
+    def __init__(self, weights, device=None, model_path=None, model_dir=None, train_fn=None):
+        import queue
+        import threading
+        self._q = queue.Queue()
+        self._lock = threading.Lock()
+        self._weights = weights
+        self._done = []                      # (round, seconds, last history entry)
+        self.error = None
+        self.device, self.model_path, self.model_dir = device, model_path, model_dir
+        self._train_fn = train_fn
+        self._thread = threading.Thread(target=self._loop, name="crl-trainer", daemon=True)
+        self._thread.start()
+
+    def submit(self, rnd, records):
+        self._raise()
+        self._q.put((rnd, list(records)))
+
+    def ready(self):
+        """Number of weight sets finished so far (monotonic)."""
+        self._raise()
+        with self._lock:
+            return len(self._done)
+
+    def latest(self):
+        with self._lock:
+            return self._weights, list(self._done)
+
+    def drain(self):
+        """Block until every submitted round is trained."""
+        self._q.join()
+        self._raise()
+
+    def close(self):
+        self._q.put(None)
+        self._thread.join()
+        self._raise()
+
+    def _raise(self):
+        if self.error is not None:
+            raise RuntimeError("the background trainer failed") from self.error
+
+    def _loop(self):
+        stream = None
+        if self._train_fn is None:
+            import torch
+            torch.cuda.set_device(self.device)
+            stream = torch.cuda.Stream(self.device)
+        while True:
+            item = self._q.get()
+            try:
+                if item is None:
+                    return
+                rnd, records = item
+                t0 = time.perf_counter()
+                if self._train_fn is not None:
+                    new, hist = self._train_fn(self._weights, records)
+                else:
+                    import torch
+                    with torch.cuda.stream(stream):
+                        new, hist = train_weights(self._weights, records, self.device, self.model_dir)
+                    stream.synchronize()
+                if self.model_path is not None:
+                    if str(self.model_path).endswith((".h5", ".hdf5")):
+                        from .keras_h5 import save_keras_h5
+                        save_keras_h5(new, self.model_path)
+                    else:
+                        np.savez(self.model_path, **new)
+                with self._lock:
+                    self._weights = new
+                    self._done.append((rnd, time.perf_counter() - t0, hist[-1] if hist else None))
+                log.info("trainer: round %d trained on %d games in %.1fs", rnd, len(records), time.perf_counter() - t0)
+            except BaseException as e:                    # surfaces at the next submit / ready / drain
+                self.error = e
+            finally:
+                self._q.task_done()
 
 
 def main(argv=None):
@@ -360,8 +519,15 @@ def main(argv=None):
     parser.add_argument("--no-train", action="store_true", help="only play and store the records")
     parser.add_argument("--rolling", action="store_true",
                         help="overlap the rounds: freed slots take the next round's games while a round's "
-                             "long games finish; a round is trained on as soon as its last game ends and "
-                             "the games under way continue on the new weights")
+                             "long games finish; a round is trained on as soon as its last game ends -- on "
+                             "rank 0, in the background, while every rank keeps playing -- and the games "
+                             "under way continue on the new weights once they are there")
+    parser.add_argument("--max-plies", type=int, default=4096,
+                        help="longest game record; a game still running there is handed over unfinished "
+                             "(result None) and its slot refilled")
+    parser.add_argument("--dist-timeout-min", type=float, default=360.0,
+                        help="process-group timeout in minutes (the default RCCL watchdog of 10 minutes is "
+                             "shorter than one training round of a large net)")
     parser.add_argument("--precision", choices=["auto", "f16", "f16x3"], default="auto",
                         help="arithmetic of the fused HIP tower: 'f16' = one fp16 MFMA per product (fastest; "
                              "1e-3 of fp32 only for soft nets), 'f16x3' = split operands, fp32-grade, ~3x the "
@@ -373,6 +539,7 @@ def main(argv=None):
     args = parser.parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO)
 
+    import datetime
     import torch
     import torch.distributed as dist
     from .model import ChessModel
@@ -385,7 +552,10 @@ def main(argv=None):
         # CRL_DIST_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
         local = int(os.environ.get("CRL_DEVICE", local))
         torch.cuda.set_device(local)
-        dist.init_process_group(os.environ.get("CRL_DIST_BACKEND", "nccl"))
+        # an explicit timeout: in the stop-and-train mode the other ranks wait in the weight broadcast
+        # for as long as rank 0 trains (20x256: ~1 400 s per 8 x 4096-game round; the watchdog default is 600 s)
+        dist.init_process_group(os.environ.get("CRL_DIST_BACKEND", "nccl"),
+                                timeout=datetime.timedelta(minutes=args.dist_timeout_min))
     os.makedirs(args.model_dir, exist_ok=True)
     path = get_model_path(args.model_dir)
     weights = path if os.path.exists(path) else None
@@ -394,15 +564,24 @@ def main(argv=None):
     per_rank = (args.games + world - 1) // world
     parallel = args.parallel or min(per_rank, 4096)
     allrecs = []
+    max_plies = args.max_plies
+    background = (BackgroundTrainer(model.weights, "cuda:%d" % local, path, args.model_dir)
+                  if (args.rolling and not args.no_train and rank == 0) else None)
 
-    def after_round(rnd, recs):
-        """Gather the round's records (RCCL), store them, train on rank 0, ship the weights."""
+    def store(rnd, recs):
+        """Gather the round's records (RCCL) and store them (rank 0)."""
         newrecs = gather_records(recs, max_plies)
         allrecs.extend(newrecs)
         if rank == 0:
             with open(os.path.join(args.model_dir, "gameplays.json"), "w") as f:
                 f.write(dumps(allrecs))
             log.info("round %d: wrote %d game records", rnd, len(allrecs))
+        return newrecs
+
+    def after_round(rnd, recs):
+        """Stop-and-train (the reference's order, selfplay.py:142-163): gather, store, train on rank 0,
+        ship the weights; every rank waits for them."""
+        newrecs = store(rnd, recs)
         if not args.no_train:
             # the reference trains in ONE process; here rank 0 trains on every rank's games and the
             # new weights go to the other ranks over RCCL (one broadcast per round).  The inference
@@ -416,7 +595,22 @@ def main(argv=None):
                 from .train import broadcast_weights
                 model.load_dict(broadcast_weights(model.weights, "cuda:%d" % local, src=0))
 
-    max_plies = 4096
+    def after_round_rolling(rnd, recs):
+        """Rolling rounds: gather, store, hand the round to rank 0's background trainer and play on."""
+        newrecs = store(rnd, recs)
+        if background is not None:
+            background.submit(rnd, newrecs)
+
+    def new_weights(k):
+        """Every rank, at the same sync index: rank 0's newest trained weights into the inference tensors
+        (one flat broadcast; in place, so the captured hipGraph stays valid)."""
+        w = background.latest()[0] if background is not None else model.weights
+        if world > 1:
+            from .train import broadcast_weights
+            w = broadcast_weights(w, "cuda:%d" % local, src=0)
+        model.load_dict(w)
+        log.info("rank %d: weight set %d loaded", rank, k)
+
     if args.rolling:
         # rounds overlap: the batch keeps refilling from the next round's ids while a round's long
         # games finish (SelfPlayRunner.run_rolling); game ids run on across rounds
@@ -425,10 +619,18 @@ def main(argv=None):
                                 total_games=args.games * args.rounds, round_size=args.games,
                                 numpy_promotion=args.numpy_promotion)
         t0 = time.perf_counter()
-        runner.run_rolling(args.rounds, on_round=after_round)
+        poll = (lambda: background.ready() if background is not None else 0) if not args.no_train else None
+        runner.run_rolling(args.rounds, on_round=after_round_rolling, poll=poll,
+                           on_news=new_weights if not args.no_train else None)
         dt = time.perf_counter() - t0
         log.info("rank %d: %d rolling rounds of %d games, %d sims in %.1fs (%.0f sims/s)", rank, args.rounds,
                  args.games, runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))
+        if not args.no_train:
+            if background is not None:
+                background.drain()                    # the last rounds' training (the other ranks wait in sync_news)
+            runner.sync_news(poll, new_weights)
+            if background is not None:
+                background.close()
         runner.close()
     else:
         for rnd in range(args.rounds):

@@ -77,14 +77,19 @@ def _empty_worker(rank, world, port, q):
     from chessrl_amd import records
     from chessrl_amd.game import uci_to_move
     mine = [] if rank == 0 else [records.GameRecord(1, [uci_to_move("d2d4")] * 5, 0, False),
-                                 records.GameRecord(3, [], None, True)]      # an empty, unfinished game
-    allr = records.gather_records(mine, max_plies=16)
-    q.put((rank, [(r.game_id, len(r.moves), r.result) for r in allr]))
+                                 records.GameRecord(3, [], None, True),      # an empty, unfinished game
+                                 records.GameRecord(5, [uci_to_move("g1f3")] * 15, None, False, truncated=True)]
+    st = {}
+    allr = records.gather_records(mine, max_plies=4096, stats=st)
+    # the blocks travel trimmed to the longest record of any rank (15 plies = 8 ints), not to max_plies
+    assert st["bytes_gathered"] == 2 * 3 * (records.HEADER + 8) * 4, st
+    q.put((rank, [(r.game_id, len(r.moves), r.result) + ((r.truncated,) if r.truncated else ()) for r in allr]))
     dist.destroy_process_group()
 
 
 def test_gather_records_with_an_empty_rank_and_an_empty_game():
-    """Ragged input: one rank finished nothing, another holds a zero-ply game with result None."""
+    """Ragged input: one rank finished nothing, another holds a zero-ply game with result None and a game
+    the runner cut off at max_plies (result None, truncated)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000)
@@ -95,7 +100,7 @@ def test_gather_records_with_an_empty_rank_and_an_empty_game():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    assert got[0] == got[1] == [(1, 5, 0), (3, 0, None)]
+    assert got[0] == got[1] == [(1, 5, 0), (3, 0, None), (5, 15, None, True)]   # the truncated flag travels
 
 
 def _rolling_worker(rank, world, port, q):
@@ -212,3 +217,97 @@ def test_host_helpers_of_round_3():
         raise AssertionError("accepted a noise row of the wrong length")
     except RuntimeError:
         pass
+
+
+def _async_train_worker(rank, world, port, q):
+    """run_rolling with a background trainer on rank 0 (the product's BackgroundTrainer with a slow CPU
+    train_fn standing in for the GPU step) and the news counter in the periodic all_reduce: nobody waits
+    for the trainer."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import BackgroundTrainer, SelfPlayRunner
+    from chessrl_amd.train import broadcast_weights
+    N, R = 4, 3
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
+    run._round_done, run.finished = {}, []
+    mine = [g for g in range(N * R) if g % world == rank]
+    finish_at = {g: 10 * (k + 1) for k, g in enumerate(mine)}      # one game every tenth move: a round per 20 moves
+    state = {"move": 0, "sims": 0}
+    last = max(finish_at.values())
+    run.active = lambda: np.array([state["move"] < last])
+
+    def play_move():
+        state["move"] += 1
+        state["sims"] += 100                                       # this rank's simulation counter
+        time.sleep(0.02)
+        for g, m in finish_at.items():
+            if m == state["move"]:
+                run.finished.append(records.GameRecord(g, [1, 2, 3], 0, True))
+                run._round_done[g // N] = run._round_done.get(g // N, 0) + 1
+
+    run.play_move = play_move
+    weights = {"w": np.zeros(3, np.float32), "meta.blocks": np.array(1), "meta.filters": np.array(8)}
+    trained_during = []
+
+    def slow_train(w, recs):                                       # 0.5 s per round, adds 1 to the weights
+        t0 = state["sims"]
+        time.sleep(0.5)
+        trained_during.append(state["sims"] - t0)                  # simulations THIS rank ran meanwhile
+        return dict(w, w=w["w"] + 1), [{"loss": 0.0}]
+
+    bg = BackgroundTrainer(weights, train_fn=slow_train) if rank == 0 else None
+    model = {"w": weights, "loaded_at": []}
+
+    def on_round(r, recs):
+        allr = records.gather_records(recs, max_plies=8)
+        assert [x.game_id for x in allr] == list(range(N * r, N * r + N))
+        if bg is not None:
+            bg.submit(r, allr)
+
+    def on_news(k):
+        w = bg.latest()[0] if bg is not None else model["w"]
+        model["w"] = broadcast_weights(w, "cpu", src=0)
+        model["loaded_at"].append((k, state["move"], state["sims"]))
+
+    poll = lambda: bg.ready() if bg is not None else 0
+    sims_at_submit = []
+    done = run.run_rolling(R, on_round=on_round, sync_every=2, poll=poll, on_news=on_news)
+    if bg is not None:
+        bg.drain()
+    run.sync_news(poll, on_news)
+    if bg is not None:
+        bg.close()
+    q.put((rank, done, float(model["w"]["w"][0]), model["loaded_at"], trained_during, state["sims"]))
+    dist.destroy_process_group()
+
+
+def test_ranks_keep_playing_while_rank_0_trains_in_the_background():
+    """Two gloo ranks, three rolling rounds, a trainer that takes 0.5 s per round on rank 0's thread:
+    rank 1's simulation counter (and rank 0's own) advances while the trainer works, every weight set
+    reaches both ranks through the news bit of the periodic all_reduce at the same sync index, and after
+    the final drain both hold the weights of the last round."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_async_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=180) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        done, w, loaded_at, _, sims = got[rank]
+        assert done == 3 and w == 3.0                              # three rounds trained, last weights everywhere
+        assert [k for k, _, _ in loaded_at] == sorted(k for k, _, _ in loaded_at) and loaded_at[-1][0] == 3
+    # same sync index on both ranks for every weight set (the collective inside on_news cannot dead-lock)
+    assert [(k, m) for k, m, _ in got[0][2]] == [(k, m) for k, m, _ in got[1][2]]
+    # rank 0 itself played on while its trainer thread worked ...
+    assert all(d > 0 for d in got[0][3][:2]), got[0][3]
+    # ... and rank 1 was never held: between two weight loads it ran simulations
+    loads1 = got[1][2]
+    assert len(loads1) >= 2 and all(b[2] > a[2] for a, b in zip(loads1, loads1[1:])), loads1

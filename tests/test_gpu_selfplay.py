@@ -38,6 +38,34 @@ def test_full_games_with_refill_match_oracle():
     run.close()
 
 
+def test_a_game_that_fills_its_record_is_handed_over_truncated_and_the_others_finish():
+    """max_plies = 64: a game still running when its record cannot take another full move is ended by
+    the runner -- result None, ``truncated`` -- instead of raising the device's capacity error; its slot is
+    refilled, every other game finishes, and every record (cut off or complete) equals the oracle's game
+    move for move as far as it goes."""
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import SelfPlayRunner
+    net = FakeNet(seed=21, prior_shift=30)
+    seed, sims, cap = 5, 6, 64
+    run = SelfPlayRunner(net.to("cuda:0"), n_parallel=3, sims=sims, seed=seed, noise=True,
+                         total_games=8, max_plies=cap)
+    recs = sorted(run.run(), key=lambda r: r.game_id)
+    assert [r.game_id for r in recs] == list(range(8))
+    cut = [r for r in recs if r.truncated]
+    assert cut and len(cut) < len(recs) and run.truncated_games == len(cut)
+    for r in recs:
+        h = oracle_game(net, r.game_id, seed, sims, True).get_history()
+        if r.truncated:
+            assert r.result is None and cap - 3 <= len(r.moves) <= cap and len(h["moves"]) > len(r.moves)
+            assert r.get_history()["moves"] == h["moves"][:len(r.moves)], r.game_id
+        else:
+            assert r.get_history()["moves"] == h["moves"] and r.result == h["result"] is not None, r.game_id
+    run.engine.ctx.sync()                                   # no sticky device error
+    run.close()
+    back = records.unpack(records.pack(recs, cap))          # the flag survives the wire format
+    assert [(b.truncated, b.result) for b in back] == [(r.truncated, r.result) for r in recs]
+
+
 def test_complete_games_with_the_real_tower_do_not_depend_on_the_policy_format():
     """48 complete games (refill, compaction of the thinning batch, noise on) with the fused HIP
     tower: once with the heads writing only the legal moves' probabilities (CRL_POLICY_LEGAL, the

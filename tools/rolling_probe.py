@@ -1,8 +1,11 @@
 """Scratch (GPU): self-play games per hour over whole games, stop-and-train rounds against rolling rounds
 (SelfPlayRunner.run_rolling) at C3: G games in lockstep, S sims/move, 10x128 random-init tower.
-python tools/rolling_probe.py [G=4096] [S=800] [rounds=3] [round_size=G]
+python tools/rolling_probe.py [G=4096] [S=800] [rounds=3] [round_size=G] [train]
 Reports when each round was handed over and, from the timeline of finished games, the rate over every
-window of `round_size` consecutively finished games (the accounting window)."""
+window of `round_size` consecutively finished games (the accounting window).  With `train` every round is
+handed to the background trainer (chessrl_amd.selfplay.BackgroundTrainer: rank 0's thread and stream) as the
+CLI's --rolling mode does, and the weights are swapped in place when a weight set is ready: games per hour
+WITH training in the loop."""
 import json
 import os
 import sys
@@ -17,7 +20,8 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N = int(sys.argv[4]) if len(sys.argv) > 4 else G
-model = ChessModel(blocks=10, filters=128, precision="f16")
+TRAIN = len(sys.argv) > 5 and sys.argv[5] == "train"
+model = ChessModel(blocks=10, filters=128, precision="f16" if not TRAIN else "auto")
 run = SelfPlayRunner(model, G, S, seed=0, noise=True, total_games=R * N, round_size=N, max_plies=4096)
 t0 = time.time()
 timeline = []                                   # (seconds, games finished so far, slots in the batch)
@@ -43,8 +47,29 @@ def on_round(r, recs):
     print(json.dumps(rounds[-1]), flush=True)
 
 
-done = run.run_rolling(R, on_round=on_round)
+bg, loads = None, []
+if TRAIN:
+    from chessrl_amd.selfplay import BackgroundTrainer
+    bg = BackgroundTrainer(model.weights, "cuda:0")
+    on_round_plain = on_round
+
+    def on_round(r, recs):
+        on_round_plain(r, recs)
+        bg.submit(r, recs)
+
+    def on_news(k):
+        model.load_dict(bg.latest()[0])
+        loads.append({"weight_set": k, "at_s": time.time() - t0, "precision": model.precision})
+        print(json.dumps(loads[-1]), flush=True)
+
+    done = run.run_rolling(R, on_round=on_round, poll=bg.ready, on_news=on_news)
+else:
+    done = run.run_rolling(R, on_round=on_round)
 total = time.time() - t0
+if bg is not None:
+    bg.drain()
+    trainer = [{"round": r, "seconds": s, "last": h} for r, s, h in bg.latest()[1]]
+    bg.close()
 tl = np.array(timeline)
 # the rate over every window of N consecutively finished games: first time the count reaches k and k + N
 windows = []
@@ -52,7 +77,9 @@ for k in range(0, int(tl[-1, 1]) - N + 1, max(1, N // 4)):
     ta = tl[np.searchsorted(tl[:, 1], k, side="left"), 0] if k > 0 else 0.0
     tb = tl[np.searchsorted(tl[:, 1], k + N, side="left"), 0]
     windows.append({"from_game": k, "seconds": float(tb - ta), "games_per_hour": N / (tb - ta) * 3600.0})
-out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 f16", "round_size": N, "rounds": rounds,
+out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 %s" % model.precision, "round_size": N, "rounds": rounds,
+       "training_in_the_loop": TRAIN, "weight_loads": loads, "trainer": trainer if TRAIN else None,
+       "seconds_until_last_round_trained": (time.time() - t0) if TRAIN else None,
        "rounds_done": done, "seconds_total": total, "games_total": int(tl[-1, 1]), "sims_run": run.sims_run,
        "sims_per_s_overall": run.sims_run / total, "games_per_hour_overall": tl[-1, 1] / total * 3600.0,
        "windows_of_round_size_finished_games": windows,
@@ -61,4 +88,4 @@ out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 f16", "round
                "that lie inside the refilled phase show the sustained rate"}
 print(json.dumps(out))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/rolling_probe.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/rolling_probe%s.json" % ("_train" if TRAIN else ""), "w"), indent=1)
