@@ -349,6 +349,30 @@ def time_record_gather(run, dist, max_plies):
             "what": "all_gather of counts + padded int32 record blocks incl. H2D/D2H staging, best of 3"}
 
 
+def agree_max(dist, x, rdev):
+    """max over ranks of a small integer (identity without a process group)."""
+    if dist is None:
+        return int(x)
+    t = torch.tensor([int(x)], dtype=torch.int64, device=rdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def every_rank(dist, values, rdev):
+    """[[values of rank 0], [values of rank 1], ...] on every rank (one all_gather of a few doubles)."""
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=rdev)
+    if dist is None:
+        return [mine.tolist()]
+    world = dist.get_world_size()
+    out = torch.zeros(world * len(values), dtype=torch.float64, device=rdev)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().view(world, len(values)).tolist()
+
+
+def spread(xs):
+    return {"min": min(xs), "mean": sum(xs) / len(xs), "max": max(xs), "ranks": list(xs)}
+
+
 def dry_run(a, rank, world, dist):
     """CRL_BENCH_DRYRUN=1 (tests, no GPU needed): the launcher / process-group / record-gather
     control flow only.  Nothing is measured and the line says so."""
@@ -362,9 +386,17 @@ def dry_run(a, rank, world, dist):
     st = {}
     rows, counts = records.gather_blocks(block, stats=st)
     assert counts == [5 + r for r in range(world)]
+    # the bench's own small collectives with synthetic per-rank numbers: the precision-mode agreement (any
+    # rank on f16x3 -> every rank), the parity gate's decision, the per-rank step and trunk times
+    rdev = torch.device("cpu")
+    mode = agree_max(dist, rank == world - 1, rdev)
+    per = every_rank(dist, [2.0 + 0.01 * rank, 1.0 + 0.001 * rank], rdev)
     if rank == 0:
         print(json.dumps({"metric": "MCTS simulations/sec at 800 sims/move", "value": None,
                           "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "mode_agreed": "f16x3" if mode else "f16",
+                          "per_rank": {"ms_per_step": spread([p[0] for p in per]),
+                                       "trunk_launch_ms": spread([p[1] for p in per])},
                           "record_gather": {"records": int(rows.shape[0]), "backend": st.get("backend")}}),
               flush=True)
 
@@ -530,14 +562,6 @@ def main():
     # collectives of the bench itself travel on the process group's own device type
     rdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
-    def agree_max(x):
-        """max over ranks of a small integer (identity without a process group)."""
-        if dist is None:
-            return int(x)
-        t = torch.tensor([int(x)], dtype=torch.int64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return int(t.item())
-
     from chessrl_amd.model import ChessModel
     from chessrl_amd.selfplay import SelfPlayRunner
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
@@ -545,7 +569,7 @@ def main():
                        seed=a.seed, fused=not a.no_fused, precision=a.precision)
     # every rank times the same arithmetic: "auto" decides per rank (same weights, same probe -- but a
     # decision at the edge of the tolerance must not leave one rank in f16x3 beside seven in f16)
-    if model.fused and agree_max(model.precision == "f16x3") and model.precision != "f16x3":
+    if model.fused and agree_max(dist, model.precision == "f16x3", rdev) and model.precision != "f16x3":
         model.set_precision("f16x3")
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
@@ -560,15 +584,8 @@ def main():
 
     def reduce_window(w):
         """(simulations of all ranks, max wall time over ranks, per-rank [ms_per_step])"""
-        tot = torch.tensor([float(w["sims"]), w["dt"]], dtype=torch.float64, device=rdev)
-        if dist is None:
-            return float(w["sims"]), w["dt"], [w["dt"] / a.steps * 1e3]
-        s = tot.clone()
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        every = torch.zeros(world * 2, dtype=torch.float64, device=rdev)
-        dist.all_gather_into_tensor(every, tot)
-        every = every.cpu().view(world, 2)
-        return s[0].item(), float(every[:, 1].max()), [float(x) / a.steps * 1e3 for x in every[:, 1]]
+        per = every_rank(dist, [w["sims"], w["dt"]], rdev)
+        return sum(p[0] for p in per), max(p[1] for p in per), [p[1] / a.steps * 1e3 for p in per]
 
     win = timed_window(run, a, barrier)
     total_sims, max_dt, rank_ms = reduce_window(win)
@@ -585,7 +602,7 @@ def main():
         parity_sets = [("complete self-play games with the timed weights (128 games x 16 sims/move)", bits, info),
                        ("the timed window's last tower inputs (512 x S1 + 512 x S2 tree leaves)", leaves, None)]
         parity = tower_error_vs_fp32(model, parity_sets, model.precision)
-    retime = agree_max(parity is not None and not parity["within_bar"] and model.precision != "f16x3")
+    retime = agree_max(dist, parity is not None and not parity["within_bar"] and model.precision != "f16x3", rdev)
     if retime:
         # the timed mode misses the bar on these weights: the headline is the fp32-grade mode's rate
         model.set_precision("f16x3")
@@ -603,12 +620,7 @@ def main():
     # every rank's trunk launch time (clock / straggler visibility when the scaling curve is run)
     eng = run.engine
     k_ms = event_time_ms(lambda: model._run_fused(eng.planes_s2), 50) if model.fused else 0.0
-    if dist is not None:
-        every = torch.zeros(world, dtype=torch.float64, device=rdev)
-        dist.all_gather_into_tensor(every, torch.tensor([k_ms], dtype=torch.float64, device=rdev))
-        rank_k_ms = [float(x) for x in every.cpu()]
-    else:
-        rank_k_ms = [k_ms]
+    rank_k_ms = [p[0] for p in every_rank(dist, [k_ms], rdev)]
 
     if rank == 0:
         G, F, B = a.games, a.filters, a.blocks
@@ -751,10 +763,7 @@ def main():
             "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,
                        "move_boundaries_inside": inside,
                        "note": "a window shorter than one move is centred mid-move"},
-            "per_rank": {"ms_per_step": {"min": min(rank_ms), "mean": sum(rank_ms) / len(rank_ms), "max": max(rank_ms),
-                                         "ranks": rank_ms},
-                         "trunk_launch_ms": {"min": min(rank_k_ms), "mean": sum(rank_k_ms) / len(rank_k_ms),
-                                             "max": max(rank_k_ms), "ranks": rank_k_ms}},
+            "per_rank": {"ms_per_step": spread(rank_ms), "trunk_launch_ms": spread(rank_k_ms)},
             "move_boundary": boundary, "value_incl_boundaries": incl,
             "moves_per_sec": rate / a.sims,
             # games/hour: steady state with refill = moves/s / moves per game, the latter read from the

@@ -219,6 +219,19 @@ def test_bench_gpus_2_starts_two_ranks_and_checks_the_world(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None
     assert out["record_gather"] == {"records": 5 + 6, "backend": "gloo"}
+    # SCALE-day shape: 8 ranks (gloo, no GPU): one line from rank 0, every rank's step and trunk times on it,
+    # and the precision mode agreed by all ranks (one rank on f16x3 puts all eight there)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["record_gather"]["records"] == sum(5 + k for k in range(8))
+    assert out["mode_agreed"] == "f16x3"
+    pr = out["per_rank"]["ms_per_step"]
+    assert len(pr["ranks"]) == 8 and pr["min"] == 2.0 and abs(pr["max"] - 2.07) < 1e-9 and pr["min"] < pr["mean"] < pr["max"]
+    assert len(out["per_rank"]["trunk_launch_ms"]["ranks"]) == 8
     # a launcher that started a different number of ranks than --gpus says is refused
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29400")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
