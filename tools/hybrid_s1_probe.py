@@ -52,6 +52,14 @@ for blocks, filters in cfgs:
         probe = model.probe_error()
         delta = probe["dpolicy_max"]
         model.set_precision("auto")
+        # the same distance in LOG space (a rounding error of the logits moves a probability by a FACTOR):
+        # max |log p16 - log p48| over the probe positions and every label that is not vanishing
+        from chessrl_amd.model import _probe_bitplanes
+        pp = _probe_bitplanes(model.device, model.PROBE_POSITIONS)
+        pa, _ = model._forward_fused(pp, precision="f16")
+        pb, _ = model._forward_fused(pp, precision="f16x3")
+        ok = pb > 1e-12
+        delta_log = float((pa[ok].log() - pb[ok].log()).abs().max())
         truth = "f16x3"
         if model.precision != truth:
             model.precision = truth                      # the search is driven by the fp32-grade mode
@@ -71,7 +79,7 @@ for blocks, filters in cfgs:
         pri16 = torch.zeros((G, 256), dtype=torch.float32, device="cuda:0")
         cols = torch.arange(256, device="cuda:0")[None, :]
         n_pos = n_diff = 0
-        margins, wrong_margins = [], []
+        margins, wrong_margins, lmargins, wrong_lmargins = [], [], [], []
         t0 = time.time()
         for s in range(steps):
             eng.phase_select_expand()
@@ -86,23 +94,34 @@ for blocks, filters in cfgs:
             b = torch.where(mask, eng.pri_s1, torch.full_like(pri16, -1.0))
             top2 = a.topk(2, dim=1).values
             margin = top2[:, 0] - torch.clamp(top2[:, 1], min=0.0)
+            lmargin = torch.where(top2[:, 1] > 0, (top2[:, 0] / top2[:, 1].clamp(min=1e-38)).log(),
+                                  torch.full_like(margin, 1e9))     # a single legal move: nothing to confuse
             differ = (a.argmax(1) != b.argmax(1)) & live
             n_pos += int(live.sum())
             n_diff += int(differ.sum())
             margins.append(margin[live].cpu().numpy())
+            lmargins.append(lmargin[live].cpu().numpy())
             if bool(differ.any()):
                 wrong_margins.append(margin[differ].cpu().numpy())
+                wrong_lmargins.append(lmargin[differ].cpu().numpy())
             eng.phase_reply()
             eng.phase_tower_s2()
         eng.ctx.sync()
         eng.close()
         margins = np.concatenate(margins)
         wrong = np.concatenate(wrong_margins) if wrong_margins else np.zeros(0)
+        lmargins = np.concatenate(lmargins)
+        lwrong = np.concatenate(wrong_lmargins) if wrong_lmargins else np.zeros(0)
         rec = {"blocks": blocks, "filters": filters, "weights": kind, "probe": probe, "s1_positions": int(n_pos),
                "replies_that_differ_f16_vs_f16x3": int(n_diff), "seconds": time.time() - t0,
                "largest_margin_of_a_differing_reply": float(wrong.max()) if len(wrong) else 0.0,
                "rule": [{"k": k, "threshold": k * delta, "fallback_fraction": float((margins < k * delta).mean()),
-                         "wrong_replies_not_caught": int((wrong >= k * delta).sum())} for k in K]}
+                         "wrong_replies_not_caught": int((wrong >= k * delta).sum())} for k in K],
+               "probe_log_distance": delta_log,
+               "largest_log_margin_of_a_differing_reply": float(lwrong.max()) if len(lwrong) else 0.0,
+               "log_rule": [{"k": k, "threshold": k * delta_log,
+                             "fallback_fraction": float((lmargins < k * delta_log).mean()),
+                             "wrong_replies_not_caught": int((lwrong >= k * delta_log).sum())} for k in (0.5, 1, 2, 4, 8)]}
         print(json.dumps(rec), flush=True)
         out["configs"].append(rec)
 os.makedirs("gpurun_out", exist_ok=True)
