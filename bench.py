@@ -73,13 +73,15 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="PyTorch-ROCm trunk instead of the HIP kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--precision", default="auto", choices=["auto", "f16", "f16x3"],
+    p.add_argument("--precision", default="auto", choices=["auto", "f16", "f16x3", "hybrid"],
                    help="fused-trunk arithmetic of the timed region.  auto (default) = what the product picks for "
                         "these weights (ChessModel's probe), and the mode that was timed is then held to the 1e-3 "
                         "bar against the fp32 tower oracle on positions of this run's own games "
                         "(tower_error_vs_fp32); if it misses the bar the window is timed again in f16x3 and THAT "
                         "is `value`.  f16 = one fp16 MFMA per product, BASELINE's 'fp16 MFMA inference'; f16x3 = "
-                        "hi/lo split operands, three MFMAs, fp32-grade.  precision_modes carries both rates")
+                        "hi/lo split operands, three MFMAs, fp32-grade; hybrid = f16x3 for every output under the "
+                        "1e-3 bar (priors and value of S2), f16 with an f16x3 fall-back for the reply choice of S1 "
+                        "(what auto picks when f16 misses its tolerance).  precision_modes carries all three rates")
     p.add_argument("--strict-steps", type=int, default=40,
                    help="steps of the other precision mode's leg timed after the main window (0 = skip)")
     p.add_argument("--parity-positions", type=int, default=4096,
@@ -389,12 +391,12 @@ def dry_run(a, rank, world, dist):
     # the bench's own small collectives with synthetic per-rank numbers: the precision-mode agreement (any
     # rank on f16x3 -> every rank), the parity gate's decision, the per-rank step and trunk times
     rdev = torch.device("cpu")
-    mode = agree_max(dist, rank == world - 1, rdev)
+    mode = agree_max(dist, 2 if rank == world - 1 else 0, rdev)
     per = every_rank(dist, [2.0 + 0.01 * rank, 1.0 + 0.001 * rank], rdev)
     if rank == 0:
         print(json.dumps({"metric": "MCTS simulations/sec at 800 sims/move", "value": None,
                           "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "mode_agreed": "f16x3" if mode else "f16",
+                          "mode_agreed": ["f16", "hybrid", "f16x3"][mode],
                           "per_rank": {"ms_per_step": spread([p[0] for p in per]),
                                        "trunk_launch_ms": spread([p[1] for p in per])},
                           "record_gather": {"records": int(rows.shape[0]), "backend": st.get("backend")}}),
@@ -569,8 +571,11 @@ def main():
                        seed=a.seed, fused=not a.no_fused, precision=a.precision)
     # every rank times the same arithmetic: "auto" decides per rank (same weights, same probe -- but a
     # decision at the edge of the tolerance must not leave one rank in f16x3 beside seven in f16)
-    if model.fused and agree_max(dist, model.precision == "f16x3", rdev) and model.precision != "f16x3":
-        model.set_precision("f16x3")
+    order = ["f16", "hybrid", "f16x3"]
+    if model.fused and dist is not None:
+        strictest = order[agree_max(dist, order.index(model.precision), rdev)]
+        if strictest != model.precision:
+            model.set_precision(strictest)
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
                          device=local, use_graph=not a.no_graph, max_plies=max_plies,
@@ -587,10 +592,14 @@ def main():
         per = every_rank(dist, [w["sims"], w["dt"]], rdev)
         return sum(p[0] for p in per), max(p[1] for p in per), [p[1] / a.steps * 1e3 for p in per]
 
+    fb0 = model.fallback_boards() if model.fused else 0
     win = timed_window(run, a, barrier)
     total_sims, max_dt, rank_ms = reduce_window(win)
     timed = {model.precision if model.fused else a.dtype: {"simulations_per_s": total_sims / max_dt,
                                                            "ms_per_step": max_dt / a.steps * 1e3}}
+    if model.fused and model.precision == "hybrid":
+        # fraction of the window's simulations whose S1 board went through the f16x3 fall-back (rank 0's games)
+        timed["hybrid"]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, win["sims"])
 
     # ---- the headline carries its own parity evidence: the mode that was timed against the fp32 oracle on
     # the same weights, on positions of complete games played with those weights and on the positions the
@@ -602,16 +611,20 @@ def main():
         parity_sets = [("complete self-play games with the timed weights (128 games x 16 sims/move)", bits, info),
                        ("the timed window's last tower inputs (512 x S1 + 512 x S2 tree leaves)", leaves, None)]
         parity = tower_error_vs_fp32(model, parity_sets, model.precision)
-    retime = agree_max(dist, parity is not None and not parity["within_bar"] and model.precision != "f16x3", rdev)
+    retime = agree_max(dist, parity is not None and not parity["within_bar"] and model.precision == "f16", rdev)
     if retime:
-        # the timed mode misses the bar on these weights: the headline is the fp32-grade mode's rate
-        model.set_precision("f16x3")
+        # the timed mode misses the bar on these weights: the headline is the rate of the mode the product
+        # falls back to (every output under the bar evaluated in f16x3)
+        model.set_precision(model.AUTO_STRICT)
+        fb0 = model.fallback_boards()
         win = timed_window(run, a, barrier)
         total_sims, max_dt, rank_ms = reduce_window(win)
-        timed["f16x3"] = {"simulations_per_s": total_sims / max_dt, "ms_per_step": max_dt / a.steps * 1e3}
+        timed[model.precision] = {"simulations_per_s": total_sims / max_dt, "ms_per_step": max_dt / a.steps * 1e3}
+        if model.precision == "hybrid":
+            timed["hybrid"]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, win["sims"])
         if rank == 0:
             failed = parity
-            parity = tower_error_vs_fp32(model, parity_sets, "f16x3")
+            parity = tower_error_vs_fp32(model, parity_sets, model.precision)
             parity["first_timed_mode"] = {k: failed[k] for k in ("mode", "dpolicy_max", "dvalue_max", "dvalue_p999",
                                                                   "positions_beyond_bar", "within_bar")}
     c0, c1, dt = win["c0"], win["c1"], win["dt"]
@@ -638,7 +651,7 @@ def main():
             # launch = 2 x (stem 73152 F + blocks 1152 F^2 B + head convs 192 F) MACs per board
             #  x G boards.
             k_flops = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
-            kern = trunk_kernel_name(F, G, int(eng.bitplanes) | (2 if model.precision == "f16x3" else 0))
+            kern = trunk_kernel_name(F, G, int(eng.bitplanes) | (2 if model._trunk_mode() == "f16x3" else 0))
             k_name = "crl_tower::%s (fused stem + %d residual blocks + head convs, %d boards)" % (kern, B, G)
             traffic, traffic_src = pmc_traffic(kern, shape)
             # what one launch must move: the encoder's planes as handed over (1 KiB of plane
@@ -706,10 +719,11 @@ def main():
         if model.fused:
             modes = {k: dict(v, window="the K timed steps") for k, v in timed.items()}
             modes[model.precision].update(trunk_kernel=kern, trunk_launch_ms=k_ms)
-            modes["f16_vs_f16x3_on_probe"] = model.probe_error()
-            other = "f16x3" if model.precision == "f16" else "f16"
-            if other not in modes and a.strict_steps > 0 and world == 1:
-                keep = model.precision
+            probe_dist = model.probe_error()
+            keep = model.precision
+            for other in ("f16", "hybrid", "f16x3"):
+                if other in modes or a.strict_steps <= 0 or world != 1:
+                    continue
                 model.set_precision(other)
                 run.begin_move()                                # fresh trees (the profiled move is abandoned)
                 grow = min(max(8, run.sims // 4), run.sims // 2)
@@ -717,23 +731,31 @@ def main():
                 for _ in range(grow):
                     eng.step()                                  # (re-captures the graph) to mid-move
                 torch.cuda.synchronize()
-                cs0 = eng.ctx.counters()["sims"]
+                cs0, fb0 = eng.ctx.counters()["sims"], model.fallback_boards()
                 ts = time.perf_counter()
                 for _ in range(n3):
                     eng.step()
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - ts
                 run._sims_in_move = grow + n3
-                k3 = trunk_kernel_name(F, G, int(eng.bitplanes) | (2 if other == "f16x3" else 0))
-                modes[other] = {"simulations_per_s": (eng.ctx.counters()["sims"] - cs0) / dts,
+                nsim = eng.ctx.counters()["sims"] - cs0
+                k3 = trunk_kernel_name(F, G, int(eng.bitplanes) | (2 if model._trunk_mode() == "f16x3" else 0))
+                modes[other] = {"simulations_per_s": nsim / dts,
                                 "ms_per_step": dts / n3 * 1e3, "window": "%d steps mid-move" % n3,
                                 "trunk_kernel": k3,
                                 "trunk_launch_ms": event_time_ms(lambda: model._run_fused(eng.planes_s2), 10),
-                                "note": ("same games, same weights, three MFMAs per product: the mode precision="
-                                         "'auto' picks when f16 is not within the bar" if other == "f16x3" else
-                                         "same games, same weights, one fp16 MFMA per product: NOT the headline -- "
-                                         "on these weights it is outside the 1e-3 bar or the probe's tolerance")}
+                                "note": {"f16x3": "same games, same weights, three MFMAs per product everywhere",
+                                         "hybrid": "same games, same weights: S2 (priors, value) in f16x3, the reply "
+                                                   "choice of S1 in f16 with an f16x3 fall-back for close calls -- the "
+                                                   "mode precision='auto' picks when f16 is not within its tolerance",
+                                         "f16": "same games, same weights, one fp16 MFMA per product: NOT the headline -- "
+                                                "on these weights it is outside the 1e-3 bar or the probe's tolerance"}[other]}
+                if other == "hybrid":
+                    modes[other]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, nsim)
+                    modes[other]["reply_margin"] = model.reply_margin
+            if model.precision != keep:
                 model.set_precision(keep)
+            modes["f16_vs_f16x3_on_probe"] = probe_dist
         cfg_name = {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
                     (4096, 800, 20, 256): "C5 per-GPU shard"}.get((G, a.sims, B, F), "custom")
         whole = tracked_whole_run()
@@ -753,10 +775,11 @@ def main():
                        "tower_precision": getattr(model, "precision", a.dtype),
                        "tower_precision_requested": a.precision, "tower_precision_probe": model.precision_probe,
                        "tower_precision_why": ("the mode first timed missed the 1e-3 bar against the fp32 oracle on these "
-                                               "weights (tower_error_vs_fp32.first_timed_mode): timed again in f16x3" if retime
+                                               "weights (tower_error_vs_fp32.first_timed_mode): timed again in " + model.precision if retime
                                                else ("asked for by --precision" if a.precision != "auto" else
                                                      "ChessModel(precision='auto'): f16 kept only if within %g of f16x3 on "
-                                                     "%d probe positions" % (model.PROBE_TOL, model.PROBE_POSITIONS))),
+                                                     "%d probe positions, else %s" % (model.PROBE_TOL, model.PROBE_POSITIONS,
+                                                                                     model.AUTO_STRICT))),
                        "trunk_kernel": kern if model.fused else None,
                        "numpy_promotion": eng.numpy_promotion,
                        "parallelism": "games sharded, no collective on the hot path"},

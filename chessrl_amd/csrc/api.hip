@@ -610,14 +610,15 @@ static TrunkPick trunk_pick(int filters, int n_boards, bool split)
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, int flags,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
-                         const void *dev_head_b_f32, void *dev_head_out_f32)
+                         const void *dev_head_b_f32, void *dev_head_out_f32, const int32_t *dev_index = nullptr)
 {
     if (filters != 64 && filters != 128 && filters != 256)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 64, 128 and 256 filters");
     if (!dev_planes_f16 || !dev_wtiles_f16 || !dev_bias_f32 || (!dev_out_f32 && !dev_head_out_f32) ||
         (dev_head_out_f32 && (!dev_head_w_f32 || !dev_head_b_f32)) || n_boards < 4 ||
         n_boards % crl_tower::BOARDS_PER_WG != 0 || n_blocks < 0 ||
-        1 + 2 * n_blocks > crl_tower::MAX_CONVS || (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)))
+        1 + 2 * n_blocks > crl_tower::MAX_CONVS || (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)) ||
+        (dev_index && (dev_out_f32 || !dev_head_out_f32 || flags != (CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT))))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: bad argument");
     typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, float *, int,
                            const float *, const float *, float *);
@@ -636,6 +637,16 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     CRL_X16(128, 2, 1, 0, 0) CRL_X16(128, 4, 1, 0, 0)
     CRL_X16(256, 1, 0, 0, 1) CRL_X16(128, 2, 1, 0, 1) CRL_X16(64, 2, 0, 0, 1) CRL_X16(64, 4, 0, 0, 1)
 #undef CRL_X16
+    if (dev_index) {
+        // the list form (hybrid precision: the boards the single-MFMA pass could not decide): the split kernels
+        // with their boards taken from the list the kernel finds in its `out` slot
+        kern = nullptr;
+#define CRL_X16I(F_, NB_, PAIR_)                                                                   \
+        if (filters == F_ && pk.nb == NB_) kern = crl_tower::k_trunk_x16<F_, NB_, 1, 0, PAIR_, 0, 1, 1>;
+        CRL_X16I(256, 1, 0) CRL_X16I(128, 2, 1) CRL_X16I(64, 2, 0) CRL_X16I(64, 4, 0)
+#undef CRL_X16I
+        dev_out_f32 = const_cast<int32_t *>(dev_index);
+    }
     if (!kern) return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: no kernel for this shape");
     hipError_t ea = allow_big_lds((const void *)kern, lds_bytes);
     if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
@@ -646,6 +657,33 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
                        (const float *)dev_head_w_f32, (const float *)dev_head_b_f32,
                        (float *)dev_head_out_f32);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
+                              const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
+                              const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
+                              const int32_t *dev_list)
+{
+    if (!dev_list) return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward_indexed: bad argument");
+    return trunk_forward(hip_stream, filters, dev_bitplanes_u64, CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT, dev_wtiles_f16x3,
+                         dev_bias_f32, nullptr, n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32,
+                         dev_list);
+}
+
+int crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
+                     float log_margin, int rows_are_logits, int32_t *dev_list)
+{
+    if (!dev_priors_f32 || !dev_counts || n_boards < 1 || !dev_list || !(log_margin >= 0.f))
+        return fail(nullptr, CRL_ERR_ARG, "crl_reply_margin: bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipError_t e = hipMemsetAsync(dev_list, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(crl_heads::k_reply_margin, dim3((unsigned)((n_boards + 3) / 4)), dim3(256), 0, st,
+                       (const float *)dev_priors_f32, (const int *)dev_counts, n_boards, log_margin,
+                       rows_are_logits ? 1 : 0, (int *)dev_list);
+    e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
 }

@@ -404,4 +404,44 @@ __global__ __launch_bounds__(256) void k_policy_normalise(float *__restrict__ po
     }
 }
 
+// ---- hybrid precision: which S1 boards need the fp32-grade trunk? ------------------------------------
+// An evaluation of S1 only chooses the opponent's reply: argmax of the policy over the legal labels
+// (agentdistributed.py:57-58).  In the hybrid mode S1 runs the single-MFMA trunk first; this kernel lists the
+// boards whose choice is not safe against that arithmetic's error: the log-margin of the two best legal
+// moves, log p1 - log p2 (= the difference of their logits: a rounding error of the trunk moves a logit,
+// i.e. a probability by a FACTOR), is below `log_margin`.  One wave per board.  list: int32 [2 + n_boards]:
+// [0] boards listed by this launch (zeroed by the caller), [1] running total of listed boards (statistics),
+// [2 + k] the boards, in no particular order (the consumers do not depend on it).
+__global__ __launch_bounds__(256) void k_reply_margin(const float *__restrict__ priors, const int *__restrict__ counts,
+                                                      int n_boards, float log_margin, int rows_are_logits,
+                                                      int *__restrict__ list)
+{
+    const int lane = threadIdx.x & 63, board = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (board >= n_boards) return;
+    int cnt = counts[board];
+    cnt = cnt > LEGAL_STRIDE ? LEGAL_STRIDE : cnt;
+    if (cnt < 2) return;                                  // no reply wanted, or a forced one
+    const float *row = priors + (size_t)board * LEGAL_STRIDE;
+    float m1 = -__builtin_inff(), m2 = -__builtin_inff();
+    for (int j = lane; j < cnt; j += 64) {
+        const float v = row[j];
+        if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) m2 = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float o1 = __shfl_xor(m1, o), o2 = __shfl_xor(m2, o);
+        const float hi = fmaxf(m1, o1), lo = fminf(m1, o1);
+        m2 = fmaxf(lo, fmaxf(m2, o2));
+        m1 = hi;
+    }
+    float margin;
+    if (rows_are_logits) margin = m1 - m2;
+    else margin = m2 > 0.f ? __logf(m1 / m2) : (m1 > 0.f ? __builtin_inff() : 0.f);
+    if (lane == 0 && !(margin >= log_margin)) {           // (NaN counts as unsafe)
+        const int k = atomicAdd(list, 1);
+        list[2 + k] = board;
+        atomicAdd(list + 1, 1);
+    }
+}
+
 }  // namespace crl_heads

@@ -112,4 +112,25 @@ __device__ inline void expand_bitplanes(const unsigned char *planes, lds_byte *l
     }
 }
 
+// the same for boards given one by one (the indexed launch: resident board k is row rows[k] of `planes`)
+template <int NB, int AROW, int ABOARD>
+__device__ inline void expand_bitplanes_rows(const unsigned char *planes, lds_byte *lds, const int (&rows)[NB], int tid)
+{
+    const unsigned long long *all = reinterpret_cast<const unsigned long long *>(planes);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int item = k * 512 + tid;
+        const int b = item >> 9, p = (item >> 3) & 63, c = item & 7;     // b == k: one board per 512 items
+        const int sq = p ^ 56;
+        const unsigned long long *m = all + (size_t)rows[k] * 128 + c * 16;
+        unsigned int w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            w[q] = (((m[2 * q] >> sq) & 1) ? 0x3C00u : 0u) | (((m[2 * q + 1] >> sq) & 1) ? 0x3C000000u : 0u);
+        lds_byte *dst = lds + b * ABOARD + p * AROW + c * 32;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst) = u32x4{w[0], w[1], w[2], w[3]};
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(dst + 16) = u32x4{w[4], w[5], w[6], w[7]};
+    }
+}
+
 }  // namespace crl_tower

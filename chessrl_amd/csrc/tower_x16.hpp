@@ -192,7 +192,14 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 // workgroup) groups, so a tile is requested two (three) groups before it is read, and inside a
 // group the six sub-steps run back to back with their fragments fetched TWO sub-steps ahead into
 // three register buffers, across tap boundaries (not across layers: those activations do not exist yet).
-template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0, int GROUP = 0, int SPLIT = 0>
+// IDX = 1 (the fall-back launch of the hybrid precision mode, crl_trunk_forward_indexed): the launch covers a
+// LIST of boards.  `out` is then not an output but the list, int32 [2 + n]: [0] = number of listed boards
+// (a workgroup beyond it exits at once: the grid is sized for the worst case, the list is written on the
+// device), [1] unused here, [2 + k] = the board (row of `planes` and of `head_out`) the k-th resident board
+// is.  A list that does not fill the last workgroup is padded with its last entry (the same board computed
+// twice writes the same values twice).  Nothing else changes: the production kernels (IDX = 0) compile as
+// they did.
+template <int F, int NB, int BITS = 0, int ALT = 0, int PAIR = 0, int GROUP = 0, int SPLIT = 0, int IDX = 0>
 __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__restrict__ planes,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -221,6 +228,18 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     const int tiles_stem = 9 * (SPLIT ? 2 : 1) * (128 / G::KT), tiles_conv = 9 * (SPLIT ? 2 : 1) * (F / G::KT);
     const int n_tiles = tiles_stem + 2 * n_blocks * tiles_conv;
     const size_t wg_board0 = (size_t)blockIdx.x * G::NB;
+    int rows[G::NB];                                    // IDX: the listed boards this workgroup holds (wave-uniform)
+    if constexpr (IDX) {
+        static_assert(BITS == 1 && ALT == 0, "the indexed launch reads plane bitboards");
+        const int *list = reinterpret_cast<const int *>(out);
+        const int listed = __builtin_amdgcn_readfirstlane(list[0]);
+        if ((int)wg_board0 >= listed) return;           // before any DMA or barrier: the whole workgroup leaves
+#pragma unroll
+        for (int b = 0; b < G::NB; b++) {
+            const int k = (int)wg_board0 + b < listed ? (int)wg_board0 + b : listed - 1;
+            rows[b] = __builtin_amdgcn_readfirstlane(list[2 + k]);
+        }
+    }
 
     static_assert(!PAIR || ((F == 128 || F == 256) && (ALT == 0 || ALT == 2 || ALT == 7 || ALT == 8)), "pair publishing: even tile counts per layer");
     static_assert(!SPLIT || ALT != 8, "the split-precision kernels run the production schedule");
@@ -242,7 +261,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
     }
 
     {   // planes (128 channels = 16 chunks per position) -> padded LDS rows; zero rows
-        if constexpr (BITS) {
+        if constexpr (IDX) {
+            expand_bitplanes_rows<G::NB, G::AROW, G::ABOARD>(planes, lds, rows, tid);
+        } else if constexpr (BITS) {
             expand_bitplanes<G::NB, G::AROW, G::ABOARD>(planes, lds, wg_board0, tid);
         } else {
             const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + wg_board0 * BOARD_BYTES);
@@ -767,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
         return;
     }
 
-    if (out) {
+    if (!IDX && out) {
 #pragma unroll
         for (int pt = 0; pt < PT; pt++) {
             const int p = pbase + 16 * pt + r;
@@ -817,7 +838,12 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
             for (int c = 0; c < NC; c++) v += scratch[i * NC + c];      // fixed order
             v += head_b[k];
-            const size_t gb = wg_board0 + (bp >> 6);
+            size_t gb = wg_board0 + (bp >> 6);
+            if constexpr (IDX) {
+                gb = (size_t)rows[0];
+#pragma unroll
+                for (int b = 1; b < G::NB; b++) gb = (bp >> 6) == b ? (size_t)rows[b] : gb;
+            }
             const int pos = bp & 63;
             head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
         }

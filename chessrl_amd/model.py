@@ -209,9 +209,19 @@ class ChessModel(object):
     #            when it is loaded: both modes evaluate a fixed probe set of positions (random playouts
     #            by the rules kernels) and "f16" is kept only if it stays within PROBE_TOL of "f16x3"
     #            on all of them (the maximum over thousands of real positions is up to 1.7x the probe's).
-    PRECISIONS = ("auto", "f16", "f16x3")
+    #   "hybrid" the 1e-3 outputs -- priors and value of S2 -- in "f16x3"; an evaluation of S1, which only
+    #            chooses the opponent's reply (argmax over the legal labels, agentdistributed.py:57-58), in
+    #            "f16" first, and only the boards whose two best legal moves lie closer than HYBRID_K x the
+    #            f16-vs-f16x3 distance of these weights (log space, measured on the probe positions) again
+    #            in "f16x3" (crl_reply_margin + crl_trunk_forward_indexed).  Measured on 1.18 M S1 positions
+    #            of real searches per net (profiles/r04/hybrid_s1_probe.json): 3-7 % of the boards fall back
+    #            on sharp nets, 1 % on Keras-initialised ones, and every reply equals the pure f16x3 reply.
+    #            What "auto" picks when f16 misses the tolerance.
+    PRECISIONS = ("auto", "f16", "f16x3", "hybrid")
     PROBE_TOL = 5e-4
     PROBE_POSITIONS = 256
+    HYBRID_K = 2.0           # margin = HYBRID_K x max |log p_f16 - log p_f16x3| on the probe positions
+    AUTO_STRICT = "hybrid"   # what "auto" runs when f16 is not within PROBE_TOL ("f16x3" = no S1 shortcut)
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
                  dtype=torch.float16, seed=0, fused=True, precision="auto"):
@@ -222,6 +232,8 @@ class ChessModel(object):
         self.precision_requested = precision
         self.precision = None                    # resolved per weight set ("f16" / "f16x3"; the dtype otherwise)
         self.precision_probe = None              # what "auto" measured
+        self.reply_margin = None                 # hybrid: log-margin below which an S1 board is evaluated again
+        self._fallback = {}                      # hybrid: batch size -> the device list of boards to evaluate again
         self.graph_epoch = 0                     # bumped when the kernel a captured graph holds changes
         self._scratch = {}                       # batch size -> slice statistics of the small-batch heads
         self.device = torch.device(device)
@@ -295,8 +307,8 @@ class ChessModel(object):
         names = [("stem", None)]
         for i in range(self.blocks):
             names += [("block%d.conv1" % i, "block%d.bn1" % i), ("block%d.conv2" % i, "block%d.bn2" % i)]
-        want_f16 = self.precision_requested in ("auto", "f16")
-        want_x3 = self.precision_requested in ("auto", "f16x3")
+        want_f16 = self.precision_requested in ("auto", "f16", "hybrid")
+        want_x3 = self.precision_requested in ("auto", "f16x3", "hybrid")
         tiles, tiles3, biases = [], [], []
 
         def planes_of(k16):
@@ -373,6 +385,17 @@ class ChessModel(object):
         [B,128] plane bitboards (the encoder's compact form; the kernel expands them on chip).
         Returns (trunk fp32 [B,8,8,F] or None, head activations fp32 [B,192] = ReLU(1x1 head
         convs): 128 policy + 64 value)."""
+        b = planes.shape[0]
+        _, heads, trunk = self._launch_fused(planes, want_trunk, precision)
+        return (trunk[:b] if want_trunk else None), heads[:b]
+
+    def _run_fused_padded(self, planes, precision=None):
+        """(the planes as the kernel saw them -- padded to a multiple of 4 boards --, the head activations of
+        all those rows): what a second launch over the same boards needs."""
+        planes_p, heads, _ = self._launch_fused(planes, False, precision)
+        return planes_p, heads
+
+    def _launch_fused(self, planes, want_trunk, precision):
         import ctypes
         from . import _lib
         b = planes.shape[0]
@@ -392,7 +415,7 @@ class ChessModel(object):
         trunk = (torch.empty((bp, 8, 8, self.filters), dtype=torch.float32, device=self.device)
                  if want_trunk else None)
         heads = torch.empty((bp, 192), dtype=torch.float32, device=self.device)
-        split = (precision or self.precision) == "f16x3"
+        split = self._trunk_mode(precision) == "f16x3"
         image = self._wtiles3 if split else self._wtiles
         if image.numel() <= 8:                   # the placeholder: this mode's weight image was never packed
             raise _lib.HipLibraryError("the weight image of precision mode %r is not packed (model built with "
@@ -408,7 +431,13 @@ class ChessModel(object):
             ctypes.c_void_p(heads.data_ptr()))
         if rc != 0:
             raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
-        return (trunk[:b] if want_trunk else None), heads[:b]
+        return planes, heads, trunk
+
+    def _trunk_mode(self, precision=None):
+        """The trunk arithmetic of a full evaluation in mode ``precision`` (default: the resolved mode):
+        "hybrid" evaluates everything but the reply choice in "f16x3"."""
+        p = precision or self.precision
+        return "f16x3" if p in ("f16x3", "hybrid") else p
 
     def set_precision(self, precision):
         """Switch the fused trunk's arithmetic mode on the loaded weights ("auto" re-runs the probe).
@@ -439,19 +468,29 @@ class ChessModel(object):
     def _resolve_precision(self):
         """Fix ``self.precision`` for the weights just packed.  "auto": evaluate the probe positions in
         both modes and keep the single-MFMA mode only if its outputs stay within PROBE_TOL of the
-        split mode's (which is itself within ~1e-4 of fp32).  A changed decision invalidates captured
+        split mode's (which is itself within ~1e-4 of fp32); otherwise AUTO_STRICT.  "hybrid" (asked for or
+        picked) also fixes the reply margin from the same probe.  A changed decision invalidates captured
         hipGraphs (``graph_epoch``; LockstepEngine re-captures)."""
         before = self.precision
-        if self.precision_requested != "auto":
+        if self.precision_requested not in ("auto", "hybrid"):
             self.precision = self.precision_requested
         else:
             planes = _probe_bitplanes(self.device, self.PROBE_POSITIONS)
             pa, va = self._forward_fused(planes, precision="f16")
             pb, vb = self._forward_fused(planes, precision="f16x3")
             dp, dv = float((pa - pb).abs().max()), float((va - vb).abs().max())
-            self.precision = "f16" if max(dp, dv) <= self.PROBE_TOL else "f16x3"
+            # the same distance in log space: a rounding error of the trunk moves a LOGIT, i.e. a probability
+            # by a factor -- what decides whether an argmax over the legal moves can flip
+            ok = pb > 1e-12
+            dlog = float((pa[ok].log() - pb[ok].log()).abs().max())
+            if self.precision_requested == "hybrid":
+                self.precision = "hybrid"
+            else:
+                self.precision = "f16" if max(dp, dv) <= self.PROBE_TOL else self.AUTO_STRICT
+            self.reply_margin = self.HYBRID_K * dlog
             self.precision_probe = {"positions": int(planes.shape[0]), "dpolicy_max": dp, "dvalue_max": dv,
-                                    "tolerance": self.PROBE_TOL, "chosen": self.precision}
+                                    "dlog_policy_max": dlog, "tolerance": self.PROBE_TOL, "chosen": self.precision,
+                                    "reply_margin": self.reply_margin if self.precision == "hybrid" else None}
         if before is not None and before != self.precision:
             self.graph_epoch += 1
 
@@ -503,19 +542,53 @@ class ChessModel(object):
         from . import _lib
         if not self.fused:
             raise _lib.HipLibraryError("forward_legal_into needs the fused HIP tower")
-        _, hp = self._run_fused(planes)
         vp = ctypes.c_void_p
-        fn = _lib.lib().crl_heads_forward_legal if stats_out is None else _lib.lib().crl_heads_forward_legal_raw
-        scratch = self._heads_scratch(hp.shape[0]) if stats_out is None else stats_out
-        rc = fn(
-            vp(torch.cuda.current_stream(self.device).cuda_stream), vp(hp.data_ptr()), hp.shape[0],
-            vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
-            vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr), vp(counts_ptr),
-            vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None),
-            vp(scratch.data_ptr()))
-        if rc != 0:
-            raise _lib.HipLibraryError("%s failed (%d)" % ("crl_heads_forward_legal" if stats_out is None
-                                                           else "crl_heads_forward_legal_raw", rc))
+        L = _lib.lib()
+        stream = vp(torch.cuda.current_stream(self.device).cuda_stream)
+        fn = L.crl_heads_forward_legal if stats_out is None else L.crl_heads_forward_legal_raw
+        who = "crl_heads_forward_legal" if stats_out is None else "crl_heads_forward_legal_raw"
+
+        def heads(hp):
+            scratch = self._heads_scratch(hp.shape[0]) if stats_out is None else stats_out
+            rc = fn(stream, vp(hp.data_ptr()), hp.shape[0],
+                    vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()), vp(self._val_w1p.data_ptr()),
+                    vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr), vp(counts_ptr),
+                    vp(priors_out.data_ptr()), vp(val_out.data_ptr() if val_out is not None else None),
+                    vp(scratch.data_ptr()))
+            if rc != 0:
+                raise _lib.HipLibraryError("%s failed (%d)" % (who, rc))
+
+        if self.precision == "hybrid" and val_out is None:
+            # S1: the reply is an argmax over the legal labels.  Single-MFMA trunk for every board; the boards
+            # whose two best legal moves are closer than the margin are listed on the device and evaluated again
+            # by the split-precision kernels (a grid for the whole batch whose surplus workgroups exit at once);
+            # the heads then run over all rows again (16 us) -- listed boards now carry fp32-grade activations
+            if planes.dtype != torch.int64:
+                raise _lib.HipLibraryError("the hybrid mode evaluates plane bitboards (the engine's default input)")
+            planes_p, hp_full = self._run_fused_padded(planes, "f16")
+            b, bp = planes.shape[0], planes_p.shape[0]
+            heads(hp_full[:b])
+            lst = self._fallback.get(bp)
+            if lst is None:
+                lst = self._fallback[bp] = torch.zeros(2 + bp, dtype=torch.int32, device=self.device)
+            rc = L.crl_reply_margin(stream, vp(priors_out.data_ptr()), vp(counts_ptr), b, float(self.reply_margin),
+                                    0 if stats_out is None else 1, vp(lst.data_ptr()))
+            if rc != 0:
+                raise _lib.HipLibraryError("crl_reply_margin failed (%d)" % rc)
+            rc = L.crl_trunk_forward_indexed(stream, self.filters, vp(planes_p.data_ptr()), vp(self._wtiles3.data_ptr()),
+                                             vp(self._wbias.data_ptr()), bp, self.blocks, vp(self._head_w.data_ptr()),
+                                             vp(self._head_b.data_ptr()), vp(hp_full.data_ptr()), vp(lst.data_ptr()))
+            if rc != 0:
+                raise _lib.HipLibraryError("crl_trunk_forward_indexed failed (%d)" % rc)
+            heads(hp_full[:b])
+            return
+        _, hp = self._run_fused(planes)
+        heads(hp)
+
+    def fallback_boards(self):
+        """hybrid: total number of S1 boards evaluated a second time since the model was built (sum over
+        the batch sizes it has served; a device-to-host read)."""
+        return int(sum(int(v[1].item()) for v in self._fallback.values()))
 
     def raw_priors_supported(self, n_boards):
         """Whether a batch of ``n_boards`` is served by the sliced heads, i.e. may leave the softmax

@@ -528,10 +528,11 @@ def main(argv=None):
     parser.add_argument("--dist-timeout-min", type=float, default=360.0,
                         help="process-group timeout in minutes (the default RCCL watchdog of 10 minutes is "
                              "shorter than one training round of a large net)")
-    parser.add_argument("--precision", choices=["auto", "f16", "f16x3"], default="auto",
+    parser.add_argument("--precision", choices=["auto", "f16", "f16x3", "hybrid"], default="auto",
                         help="arithmetic of the fused HIP tower: 'f16' = one fp16 MFMA per product (fastest; "
                              "1e-3 of fp32 only for soft nets), 'f16x3' = split operands, fp32-grade, ~3x the "
-                             "tower time, 'auto' = f16 where a probe shows it within the bar, else f16x3")
+                             "tower time, 'hybrid' = f16x3 for priors and values, f16 with an f16x3 fall-back for "
+                             "the reply choice, 'auto' = f16 where a probe shows it within the bar, else hybrid")
     parser.add_argument("--numpy-promotion", choices=["auto", "nep50", "legacy"], default="auto",
                         help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87): 'legacy' = the float64 "
                              "product of the reference's pinned numpy 1.17.2, 'nep50' = the float32 product "

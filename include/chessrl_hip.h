@@ -69,7 +69,7 @@ typedef struct crl_ctx crl_ctx;
  * signature hands the GPU garbage pointers).  crl_source_hash(): sha256 over the sources (csrc/ + this
  * header + compiler flags) the library was built from, as chessrl_amd/_lib.py computes it; the string
  * is also findable in the file itself behind the marker "CRL_SRC_HASH=".  No reference counterpart. */
-#define CRL_ABI_VERSION 4
+#define CRL_ABI_VERSION 5
 int  crl_abi_version(void);
 const char *crl_source_hash(void);
 
@@ -235,6 +235,25 @@ int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *d
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
                          const void *dev_head_b_f32, void *dev_head_out_f32);
+
+/* Hybrid precision (ChessModel(precision="hybrid")).  An evaluation of S1 only chooses the opponent's reply
+ * -- argmax of the policy over the legal labels (agentdistributed.py:57-58 -> mctree.py:244-250) -- so S1 runs
+ * the single-MFMA trunk first and only the boards whose choice is not safe against that arithmetic's error are
+ * evaluated again with CRL_TRUNK_SPLIT; S2 (priors and value: the 1e-3 outputs) always runs CRL_TRUNK_SPLIT.
+ * crl_reply_margin lists the unsafe boards from the legal priors (or logits) of the first pass: board b is
+ * listed when it has at least two legal moves and log p1 - log p2 of its two best ones (the difference of
+ * their logits) is below log_margin.  dev_list: int32 [2 + n_boards]: [0] boards listed by this call, [1]
+ * running total over all calls on this buffer (statistics; zero it once), [2 + k] the boards (unordered).
+ * crl_trunk_forward_indexed evaluates exactly the listed boards (rows of dev_bitplanes_u64 / dev_head_out_f32;
+ * other rows of dev_head_out_f32 are left as they are): the CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT kernels with a
+ * grid for n_boards whose surplus workgroups exit at once -- the list never leaves the device, the launch sequence
+ * is fixed and captures into a hipGraph.  Stateless. */
+int  crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
+                      float log_margin, int rows_are_logits, int32_t *dev_list);
+int  crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
+                               const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
+                               const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
+                               const int32_t *dev_list);
 
 /* crl_trunk_forward with the input given as plane bitboards (CRL_PLANES_BITS), uint64
  * [n_boards][128]; everything else as above. */

@@ -76,7 +76,7 @@ def test_tower_within_1e3_on_real_selfplay_positions(blocks, filters, weights):
                                             N_POSITIONS, dp.max(), np.quantile(dp, 0.999), dv.max(), np.quantile(dv, 0.999)))
     assert dp.max() <= 1e-3 and dv.max() <= 1e-3, (model.precision, dp.max(), dv.max())
     if weights == "sharp":
-        assert model.precision == "f16x3"
+        assert model.precision == "hybrid"                          # every output under the bar in f16x3 arithmetic
         # negative control: one fp16 MFMA per product does NOT meet the bar on this net -- the
         # comparison above is able to fail; bounded drift (measured 6e-3 .. 2.4e-2)
         p16, v16 = model._forward_fused(x_bits, precision="f16")
@@ -101,7 +101,7 @@ def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
     _, planes = _positions()
     easy = tower_oracle.init_weights(2, 64, seed=4)
     sharp = tower_oracle.calibrated_weights(2, 64, planes[:256], seed=7)
-    for mode in ("f16", "f16x3"):
+    for mode in ("f16", "f16x3", "hybrid"):
         assert ChessModel(weights=sharp, precision=mode).precision == mode
     with pytest.raises(ValueError):
         ChessModel(weights=easy, precision="fp64")
@@ -112,12 +112,112 @@ def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
     eng.search(8)
     first = eng._graph
     model.load_dict(sharp)                                          # in place, under the captured graph
-    assert model.precision == "f16x3" and model.graph_epoch == 1
+    assert model.precision == "hybrid" and model.graph_epoch == 1 and model.reply_margin > 0
     eng.search(8)
-    assert eng._graph is not first                                  # re-captured with the split kernel
+    assert eng._graph is not first                                  # re-captured with the split kernels
     rc = eng.root_children()
     assert (rc["root_visits"] == 9).all()
     eng.close()
+
+
+def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exactly_those():
+    """The two entry points of the hybrid mode through the C-ABI: crl_reply_margin against numpy (both row
+    formats: probabilities and logits; boards with fewer than two legal moves never listed), and
+    crl_trunk_forward_indexed: listed rows of the head activations become the split-precision kernel's bits,
+    every other row keeps the bits it had (64, 128 and 256 filters, lists that do not fill a workgroup)."""
+    import ctypes
+    from chessrl_amd import _lib, model as M
+    from chessrl_amd.model import ChessModel
+    vp = ctypes.c_void_p
+    L = _lib.lib()
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(3)
+    n = 300
+    counts = rng.integers(0, 60, n).astype(np.int32)
+    counts[:4] = [0, 1, 2, 218]
+    for logits in (False, True):
+        rows = rng.normal(0, 1.0, (n, 256)).astype(np.float32)
+        if not logits:
+            rows = np.exp(rows) / 50.0
+        rows[5, :counts[5]] = rows[5, 0]                              # an exact tie is a close call
+        thr = 0.05
+        want = set()
+        for b in range(n):
+            if counts[b] >= 2:
+                top = np.sort(rows[b, :counts[b]])[::-1][:2].astype(np.float64)
+                margin = top[0] - top[1] if logits else np.log(top[0] / top[1])
+                if margin < thr * (1 - 1e-4):
+                    want.add(b)
+                elif margin < thr * (1 + 1e-4):
+                    want.add(-1)                                      # too close to the threshold to assert
+        lst = torch.full((2 + n,), -5, dtype=torch.int32, device="cuda")
+        lst[1] = 100
+        assert L.crl_reply_margin(st, vp(torch.from_numpy(rows).cuda().data_ptr()), vp(torch.from_numpy(counts).cuda().data_ptr()),
+                                  n, thr, int(logits), vp(lst.data_ptr())) == 0
+        got = lst.cpu().numpy()
+        listed = set(got[2:2 + got[0]].tolist())
+        assert got[1] == 100 + got[0] and len(listed) == got[0]
+        assert listed - want <= set() or -1 in want
+        assert (want - {-1}) <= listed and 5 in listed and not ({0, 1} & listed)
+    for blocks, filters, n in ((1, 64, 64), (1, 64, 1024), (1, 128, 64), (1, 256, 64)):
+        m = ChessModel(blocks=blocks, filters=filters, seed=5, precision="hybrid")
+        planes = M._probe_bitplanes(m.device, 256)[:64].repeat(n // 64, 1).contiguous()
+        planes[:, 3] ^= torch.arange(n, device="cuda")               # every board different
+        _, h16 = m._run_fused(planes, precision="f16")
+        _, h48 = m._run_fused(planes, precision="f16x3")
+        assert not torch.equal(h16, h48)
+        for pick in ([0], [5, 17, 40], list(range(1, n, 3)), []):
+            lst = torch.zeros(2 + n, dtype=torch.int32, device="cuda")
+            lst[0] = len(pick)
+            lst[2:2 + len(pick)] = torch.tensor(pick, dtype=torch.int32)[torch.randperm(len(pick))] if pick else 0
+            hp = h16.clone()
+            assert L.crl_trunk_forward_indexed(st, filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
+                                               vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()),
+                                               vp(m._head_b.data_ptr()), vp(hp.data_ptr()), vp(lst.data_ptr())) == 0
+            torch.cuda.synchronize()
+            mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+            mask[pick] = True
+            assert torch.equal(hp[mask], h48[mask]) and torch.equal(hp[~mask], h16[~mask]), (filters, n, len(pick))
+
+
+def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
+    """precision="hybrid" on a sharp net: S2 in f16x3, S1's reply choice in f16 with the listed close calls
+    evaluated again in f16x3.  512 games x 64 simulations from positions all over the game: the trees
+    (visits, value sums, priors, stored replies) are those of the pure f16x3 search bit for bit, a
+    minority of the S1 boards went through the fall-back, and the pure f16 search -- the negative control --
+    does NOT reproduce them (its replies differ somewhere)."""
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    _, planes = _positions()
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+    G, sims = 512, 64
+    rng = np.random.RandomState(11)
+    target = rng.randint(0, 120, size=G)
+    picks = rng.random_sample((int(target.max()), G))
+    out = {}
+    for mode in ("f16x3", "hybrid", "f16"):
+        model = ChessModel(weights=sharp, precision=mode)
+        eng = LockstepEngine(model, G, sims)
+        eng.reset()
+        for ply in range(int(target.max())):                         # the same random playouts for every mode
+            moves, counts = eng.ctx.legal_moves()
+            pick = (picks[ply] * np.maximum(counts, 1)).astype(np.int64)
+            mv = np.where((target > ply) & (counts > 0), moves[np.arange(G), pick], 0xFFFF).astype(np.uint16)
+            eng.ctx.push_moves(mv)
+        eng.search(sims)
+        out[mode] = (eng.root_children(), eng.ctx.counters(), model.fallback_boards() if mode == "hybrid" else 0)
+        eng.close()
+    a, b = out["f16x3"][0], out["hybrid"][0]
+    assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
+    assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+    assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
+    assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
+    s1 = out["hybrid"][1]["sims"]
+    fb = out["hybrid"][2]
+    print("hybrid: %d of %d S1 boards evaluated twice (%.1f %%)" % (fb, s1, 100.0 * fb / s1))
+    assert 0 < fb < 0.3 * s1
+    c = out["f16"][0]
+    assert not (np.array_equal(a["replies"], c["replies"]) and np.array_equal(a["visits"], c["visits"]))
 
 
 def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu():

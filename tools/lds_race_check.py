@@ -36,6 +36,7 @@ VCC, M0, EXEC = 106, 124, 126
 KERNARG = {0x00: 0x10000000, 0x08: 0x20000000, 0x10: 0x30000000, 0x18: 0x40000000,     # planes, wts, bias, out
            0x28: 0x50000000, 0x30: 0x60000000, 0x38: 0x70000000}                         # head_w, head_b, head_out
 KERNARG_BASE = 0x7F000000
+LIST_BASE = 0x48000000      # IDX kernels: their `out` slot holds the list [n listed, -, boards...]
 
 
 class EmuError(RuntimeError):
@@ -116,7 +117,7 @@ def parse_kernel(lines):
 
 
 class Wave(object):
-    def __init__(self, ins, labels, wave, n_blocks, wg=0, want_out=False, want_heads=True):
+    def __init__(self, ins, labels, wave, n_blocks, wg=0, want_out=False, want_heads=True, listed=None):
         self.ins, self.labels, self.wave = ins, labels, wave
         self.s = [None] * 128                     # None = unknown
         self.v = np.zeros((1024, 64), dtype=U32)  # v0..v511, a0..a511
@@ -131,6 +132,9 @@ class Wave(object):
         self.args = dict(KERNARG)
         if not want_out:
             self.args[0x18] = 0
+        self.listed = listed                      # IDX kernels: how many boards the list holds
+        if listed is not None:
+            self.args[0x18] = LIST_BASE
         if not want_heads:
             self.args[0x38] = 0
         self.n_blocks = n_blocks
@@ -441,7 +445,10 @@ class Wave(object):
             idx, _ = _sreg(t[0])
             for i in range(n):
                 val = None
-                if base == KERNARG_BASE:
+                if self.listed is not None and base is not None and LIST_BASE <= base + off + 4 * i < LIST_BASE + 4096:
+                    word = (base + off + 4 * i - LIST_BASE) // 4
+                    val = self.listed if word == 0 else (0 if word == 1 else (7 * (word - 2) + 3) & MASK32)
+                elif base == KERNARG_BASE:
                     o = off + 4 * i
                     if o == 0x20:
                         val = self.n_blocks
@@ -638,9 +645,12 @@ class Wave(object):
             b, kb = self.vsrc64(t[2])
             sh = a.astype(u64) & u64(63)
             self.vdst64(t[0], (b << sh) if base == "v_lshlrev_b64" else (b >> sh), ka & kb)
-        elif base == "v_mad_u64_u32":
+        elif base in ("v_mad_u64_u32", "v_mad_i64_i32"):
             a, ka = src(2)
             b, kb = src(3)
+            if base == "v_mad_i64_i32":                              # signed 32 x 32 -> 64
+                a = a.astype(np.int32).astype(np.int64).astype(u64)
+                b = b.astype(np.int32).astype(np.int64).astype(u64)
             c, kc = (np.full(64, _imm(t[4]) & 0xFFFFFFFFFFFFFFFF, u64), self._all) if _imm(t[4]) is not None else self.vsrc64(t[4])
             self.vdst64(t[0], a.astype(u64) * b.astype(u64) + c, ka & kb & kc)
             self.vunknown(t[1])
@@ -730,9 +740,9 @@ class Wave(object):
             self.vunknown(t[0])
 
 
-def check_workgroup(ins, labels, n_blocks, lds_bytes=160 * 1024, want_out=False):
+def check_workgroup(ins, labels, n_blocks, lds_bytes=160 * 1024, want_out=False, listed=None):
     """Emulate the 8 waves of workgroup 0 and cross-check their LDS traffic epoch by epoch."""
-    waves = [Wave(ins, labels, w, n_blocks, want_out=want_out).run() for w in range(8)]
+    waves = [Wave(ins, labels, w, n_blocks, want_out=want_out, listed=listed).run() for w in range(8)]
     findings = []
     for w in waves:
         for kind, line, msg in w.findings:
@@ -811,8 +821,11 @@ def kernels_of(path):
 def check_kernel(args):
     tmpl, seg, n_blocks = args
     ins, labels = parse_kernel(seg)
+    # an indexed kernel (8th template argument) takes its boards from a list: one listed board, so that a
+    # workgroup of several boards runs with its padding (the last entry repeated)
+    indexed = len(tmpl.split(",")) > 7 and tmpl.split(",")[7] == "1"
     try:
-        findings, stats = check_workgroup(ins, labels, n_blocks)
+        findings, stats = check_workgroup(ins, labels, n_blocks, listed=1 if indexed else None)
     except EmuError as e:
         findings, stats = ["emulation stopped: %s" % e], {}
     return tmpl, findings, stats
