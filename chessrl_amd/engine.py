@@ -259,7 +259,10 @@ class LockstepEngine(object):
         self.phase_tower_s2()
 
     def _capture(self):
-        # warm the evaluator (library handles, autotuning) outside of capture
+        # warm the evaluator (library handles, autotuning, buffers it keeps between calls) outside of capture
+        prepare = getattr(self.evaluator, "prepare", None)
+        if prepare is not None:
+            prepare(self.G)
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):

@@ -585,6 +585,16 @@ class ChessModel(object):
         _, hp = self._run_fused(planes)
         heads(hp)
 
+    def prepare(self, n_boards):
+        """Allocate what an evaluation of ``n_boards`` keeps between calls (the hybrid mode's device list with its
+        running counter) NOW: LockstepEngine calls this before it captures its hipGraph, so that no buffer
+        is created -- and zero-filled at every replay -- inside the captured step."""
+        bp = (int(n_boards) + 3) // 4 * 4
+        if self.fused and bp not in self._fallback:
+            self._fallback[bp] = torch.zeros(2 + bp, dtype=torch.int32, device=self.device)
+        if self.fused:
+            self._heads_scratch(int(n_boards))
+
     def fallback_boards(self):
         """hybrid: total number of S1 boards evaluated a second time since the model was built (sum over
         the batch sizes it has served; a device-to-host read)."""
