@@ -187,11 +187,17 @@ def test_c5_size_one_move_properties():
     torch.cuda.empty_cache()
 
 
-def test_c3_size_one_move_in_split_precision_and_the_reference_network():
-    """The split-precision trunk (f16x3: three MFMAs per product) at C3 size, and the network the
+def test_c3_size_one_move_in_split_precision_hybrid_and_the_reference_network():
+    """The split-precision trunk (f16x3: three MFMAs per product) and the hybrid mode at C3 size, and the network the
     reference itself builds (model.py:33-37: 10 blocks x 256 filters) at 2048 games x 200 sims."""
     a = _one_move_at_size(4096, 800, 10, 128, seed=3, precision="f16x3")
     assert a["depth"] > 2.0
+    torch.cuda.empty_cache()
+    # the hybrid mode (S2 in f16x3, the reply choice of S1 in f16 with an f16x3 fall-back for the close calls)
+    # at the same size: 3.3 million S1 evaluations -- and the trees of the pure f16x3 search, visit for visit
+    h = _one_move_at_size(4096, 800, 10, 128, seed=3, precision="hybrid")
+    assert np.array_equal(a["visits"], h["visits"]) and np.array_equal(a["nchild"], h["nchild"])
+    torch.cuda.empty_cache()
     b = _one_move_at_size(2048, 200, 10, 256, seed=4, precision="f16")
     print("C3 f16x3: depth %.2f; 10x256: depth %.2f" % (a["depth"], b["depth"]))
     torch.cuda.empty_cache()

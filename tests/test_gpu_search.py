@@ -297,8 +297,8 @@ def test_tower_within_1e3_of_fp32_oracle(blocks, filters, weights, dtype):
          else _sharp_weights(blocks, filters))
     model, eng, planes, (pol, val), (epol, eval_), dp, dv = _tower_errors(w, dtype)
     assert model.fused == (filters in (64, 128, 256) and dtype == "float16")
-    if model.fused and weights == "sharp":       # precision="auto": the split mode wherever one MFMA per product is not enough
-        assert model.precision == "f16x3"
+    if model.fused and weights == "sharp":       # precision="auto": split arithmetic wherever one MFMA per product is not enough
+        assert model.precision == "hybrid"
     if weights == "sharp":
         assert float(epol.max()) > 0.2 and float(eval_.abs().max()) > 0.5
     print("tower %dx%d %s %s fused=%d: max|dpolicy|=%.3g max|dvalue|=%.3g" %
