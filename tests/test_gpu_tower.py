@@ -220,12 +220,15 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
     assert not (np.array_equal(a["replies"], c["replies"]) and np.array_equal(a["visits"], c["visits"]))
 
 
-def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu():
+@pytest.mark.parametrize("disturbance", ["disturb", "stream"])
+def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu(disturbance):
     """Launch-to-launch identity of every trunk kernel family (64 / 128 / 256 filters, both
-    precision modes, both workgroup geometries) while a second process hammers the GPU with small
-    kernels and context churn: its workgroups share our CUs, LDS latencies jitter, and a kernel that
-    reads a register before its hand-counted ``s_waitcnt`` has made it valid shows different bits
-    (what tools/check_asm_hazards.py looks for statically; this is the dynamic half)."""
+    precision modes, both workgroup geometries, and the indexed kernels of the hybrid mode) while a second
+    process disturbs the GPU -- ``disturb``: small kernels and context churn: its workgroups share our CUs, LDS
+    latencies jitter, and a kernel that reads a register before its hand-counted ``s_waitcnt lgkmcnt`` has
+    made it valid shows different bits (static half: tools/check_asm_hazards.py); ``stream``: two 4-GiB
+    buffers copied back and forth through every L2 channel: the weight tiles' LDS-DMA arrives late, and a
+    ring slot read before its counted ``vmcnt`` wait + barrier shows (static half: tools/lds_race_check.py)."""
     import hashlib
     import os
     import subprocess
@@ -233,8 +236,13 @@ def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu():
     from chessrl_amd import model as M
     from chessrl_amd.model import ChessModel
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import ctypes
+    import time
+    from chessrl_amd import _lib
     disturber = subprocess.Popen([sys.executable, os.path.join(root, "tools", "trunk_stability_probe.py"),
-                                  "disturb", "100000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                  disturbance, "100000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    time.sleep(8)                                                    # let it get going (imports, allocation)
+    vp = ctypes.c_void_p
     try:
         for blocks, filters, n in ((1, 64, 256), (1, 64, 2048), (2, 128, 256), (2, 128, 2048), (1, 256, 256), (1, 256, 1024)):
             m = ChessModel(blocks=blocks, filters=filters, seed=5, precision="f16")
@@ -249,6 +257,22 @@ def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu():
                     seen.add(hashlib.md5(hp.cpu().numpy().tobytes()).hexdigest())
                 assert disturber.poll() is None, "the disturber ended early"
                 assert len(seen) == 1, (blocks, filters, n, mode, len(seen))
+            # the indexed split kernels (hybrid mode): every third board listed, onto f16 activations
+            lst = torch.zeros(2 + n, dtype=torch.int32, device="cuda")
+            pick = torch.arange(0, n, 3, dtype=torch.int32)
+            lst[0] = len(pick)
+            lst[2:2 + len(pick)] = pick
+            _, base = m._run_fused(planes, precision="f16")
+            seen = set()
+            for _ in range(40):
+                hp = base.clone()
+                assert _lib.lib().crl_trunk_forward_indexed(
+                    vp(torch.cuda.current_stream().cuda_stream), filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
+                    vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()), vp(m._head_b.data_ptr()),
+                    vp(hp.data_ptr()), vp(lst.data_ptr())) == 0
+                torch.cuda.synchronize()
+                seen.add(hashlib.md5(hp.cpu().numpy().tobytes()).hexdigest())
+            assert len(seen) == 1, (blocks, filters, n, "indexed", len(seen))
     finally:
         disturber.kill()
         disturber.wait()

@@ -3,7 +3,7 @@
 # (tools/trunk_stability_probe.py disturb): results that depend on timing show up as failures.
 #   bash tools/disturbed_suite.sh [pytest files ...]     (default: rules, search, self-play)
 cd $GRAFT_REPO_ROOT
-python tools/trunk_stability_probe.py disturb 100000 > /dev/null 2>&1 &
+python tools/trunk_stability_probe.py ${DISTURB:-disturb} 100000 > /dev/null 2>&1 &
 D=$!
 FILES=${@:-tests/test_gpu_rules.py tests/test_gpu_search.py tests/test_gpu_selfplay.py}
 python -m pytest $FILES -q -x -m gpu 2>&1 | tail -5

@@ -3,7 +3,10 @@ process keeps the GPU busy (its workgroups share CUs and LDS bandwidth with ours
 jitter)?  A kernel that touches a register before its hand-counted wait has made it valid passes every
 single-process test and fails here (round 3: the 64-filter split-precision kernels, 45-90 % of the
 launches wrong; cause and static check: tools/check_asm_hazards.py).
-    python tools/trunk_stability_probe.py disturb 400 &  python tools/trunk_stability_probe.py measure 150"""
+    python tools/trunk_stability_probe.py disturb 400 &  python tools/trunk_stability_probe.py measure 150
+A second disturber, ``stream N``, delays the OTHER side of the pipeline: it streams two 4-GiB buffers through
+the L2s and HBM (copies, N times), so that the weight tiles' LDS-DMA (L2 -> LDS) arrives late and a ring slot
+read before its counted ``vmcnt`` wait + barrier shows (static counterpart: tools/lds_race_check.py)."""
 import ctypes, hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +19,16 @@ if role == "disturb":                     # what the other rank's start-up does:
         M._PROBE.clear()
         M._probe_bitplanes(torch.device("cuda:0"), 256)
     print("disturber done", flush=True)
+elif role == "stream":                    # a bandwidth hog: 8 GiB of traffic per iteration through every L2 channel
+    a = torch.empty(1 << 30, dtype=torch.float32, device="cuda:0")          # 4 GiB
+    b = torch.empty(1 << 30, dtype=torch.float32, device="cuda:0")
+    for rep in range(int(sys.argv[2])):
+        b.copy_(a)
+        a.copy_(b)
+        if rep % 16 == 15:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    print("streamer done", flush=True)
 else:
     reps = int(sys.argv[2])
     for blocks, filters, n in ((1, 64, 256), (1, 64, 2048), (2, 128, 256), (2, 128, 2048), (1, 256, 256), (1, 256, 1024)):
