@@ -88,6 +88,10 @@ def parse():
                    help="positions of complete self-play games (played with the timed weights) on which the timed "
                         "tower mode is compared with the fp32 oracle after the timed region; 0 = skip "
                         "(tower_error_vs_fp32 null, no claim)")
+    p.add_argument("--weights", default=None,
+                   help="evaluate a weight file (.npz / Keras .h5; --blocks / --filters are taken from it) instead of a "
+                        "random-init net: NOT the metric's configuration (BASELINE quotes random-init nets) -- for "
+                        "measuring what the product runs once a net is trained; the line says so in config.workload")
     p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
                    help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
@@ -568,7 +572,8 @@ def main():
     from chessrl_amd.selfplay import SelfPlayRunner
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[a.dtype]
     model = ChessModel(blocks=a.blocks, filters=a.filters, device="cuda:%d" % local, dtype=tdt,
-                       seed=a.seed, fused=not a.no_fused, precision=a.precision)
+                       seed=a.seed, fused=not a.no_fused, precision=a.precision, weights=a.weights)
+    a.blocks, a.filters = model.blocks, model.filters          # (a weight file brings its own architecture)
     # every rank times the same arithmetic: "auto" decides per rank (same weights, same probe -- but a
     # decision at the edge of the tolerance must not leave one rank in f16x3 beside seven in f16)
     order = ["f16", "hybrid", "f16x3"]
@@ -767,8 +772,10 @@ def main():
             "ms_per_step": max_dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: %d self-play games in lockstep per GPU, %d sims/move, "
-                                   "%d-block/%d-filter random-init tower, standard start position, "
-                                   "Dirichlet noise on" % (cfg_name, G, a.sims, B, F),
+                                   "%d-block/%d-filter %s tower, standard start position, "
+                                   "Dirichlet noise on" % (cfg_name if a.weights is None else "custom (trained weights)", G, a.sims, B, F,
+                                                           "random-init" if a.weights is None else
+                                                           "TRAINED (%s)" % os.path.basename(a.weights)),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
                        "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",

@@ -678,7 +678,8 @@ int crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t
     if (!dev_priors_f32 || !dev_counts || n_boards < 1 || !dev_list || !(log_margin >= 0.f))
         return fail(nullptr, CRL_ERR_ARG, "crl_reply_margin: bad argument");
     hipStream_t st = (hipStream_t)hip_stream;
-    hipError_t e = hipMemsetAsync(dev_list, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(crl_heads::k_zero_word, dim3(1), dim3(64), 0, st, (int *)dev_list);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     hipLaunchKernelGGL(crl_heads::k_reply_margin, dim3((unsigned)((n_boards + 3) / 4)), dim3(256), 0, st,
                        (const float *)dev_priors_f32, (const int *)dev_counts, n_boards, log_margin,

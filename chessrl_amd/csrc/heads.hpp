@@ -412,6 +412,13 @@ __global__ __launch_bounds__(256) void k_policy_normalise(float *__restrict__ po
 // i.e. a probability by a FACTOR), is below `log_margin`.  One wave per board.  list: int32 [2 + n_boards]:
 // [0] boards listed by this launch (zeroed by the caller), [1] running total of listed boards (statistics),
 // [2 + k] the boards, in no particular order (the consumers do not depend on it).
+// (the list's counter is zeroed by a kernel, not by hipMemsetAsync: a 4-byte memset node captured into a
+// hipGraph did not run at replay on this stack -- the counter kept growing, the list overflowed)
+__global__ __launch_bounds__(64) void k_zero_word(int *__restrict__ word)
+{
+    if (threadIdx.x == 0) *word = 0;
+}
+
 __global__ __launch_bounds__(256) void k_reply_margin(const float *__restrict__ priors, const int *__restrict__ counts,
                                                       int n_boards, float log_margin, int rows_are_logits,
                                                       int *__restrict__ list)

@@ -183,9 +183,9 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
 def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
     """precision="hybrid" on a sharp net: S2 in f16x3, S1's reply choice in f16 with the listed close calls
     evaluated again in f16x3.  512 games x 64 simulations from positions all over the game: the trees
-    (visits, value sums, priors, stored replies) are those of the pure f16x3 search bit for bit, a
-    minority of the S1 boards went through the fall-back, and the pure f16 search -- the negative control --
-    does NOT reproduce them (its replies differ somewhere)."""
+    (visits, value sums, priors, stored replies) are those of the pure f16x3 search bit for bit -- for two
+    consecutive moves under one captured hipGraph --, a minority of the S1 boards went through the fall-back,
+    and the pure f16 search -- the negative control -- does NOT reproduce them (its replies differ somewhere)."""
     from chessrl_amd.engine import LockstepEngine
     from chessrl_amd.model import ChessModel
     _, planes = _positions()
@@ -205,13 +205,24 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
             mv = np.where((target > ply) & (counts > 0), moves[np.arange(G), pick], 0xFFFF).astype(np.uint16)
             eng.ctx.push_moves(mv)
         eng.search(sims)
-        out[mode] = (eng.root_children(), eng.ctx.counters(), model.fallback_boards() if mode == "hybrid" else 0)
+        first = eng.root_children()
+        # a second move under the same captured graph (the list's counter must start from zero at every step:
+        # a 4-byte memset node did not replay on this stack and the list overflowed from the second move on)
+        chosen = np.where(first["nchild"] > 0, np.maximum(first["visits"].argmax(1), 0), -1).astype(np.int32)
+        eng.advance(chosen)
+        eng.search(sims)
+        if mode == "hybrid":
+            lst = model._fallback[G].cpu().numpy()
+            assert 0 <= lst[0] <= G and len(set(lst[2:2 + lst[0]].tolist())) == lst[0]      # one step's list, no repeats
+        out[mode] = (first, eng.ctx.counters(), model.fallback_boards() if mode == "hybrid" else 0, eng.root_children())
         eng.close()
-    a, b = out["f16x3"][0], out["hybrid"][0]
-    assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
-    assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
-    assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
-    assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
+    for k in (0, 3):
+        a, b = out["f16x3"][k], out["hybrid"][k]
+        assert np.array_equal(a["nchild"], b["nchild"]) and np.array_equal(a["visits"], b["visits"])
+        assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+        assert np.array_equal(a["priors"].view(np.uint32), b["priors"].view(np.uint32))
+        assert np.array_equal(a["replies"], b["replies"]) and np.array_equal(a["moves"], b["moves"])
+    a = out["f16x3"][0]
     s1 = out["hybrid"][1]["sims"]
     fb = out["hybrid"][2]
     print("hybrid: %d of %d S1 boards evaluated twice (%.1f %%)" % (fb, s1, 100.0 * fb / s1))

@@ -11,7 +11,7 @@ mkdir -p $O
 pmc() {   # name counter cmd...
   local name=$1 ctr=$2; shift 2
   rm -rf /tmp/pm_$name
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pm_$name -- "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pm_$name -- "$@" > /dev/null 2>&1
   find /tmp/pm_$name -name "*counter_collection.csv" -exec cp {} $O/${name}_${ctr}.csv \;
 }
 pmc trunk128 FETCH_SIZE python3 $R/tools/trunk_once.py 10 128 4096
@@ -29,7 +29,7 @@ pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
 for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
   find /tmp/st_$name -name "*kernel_stats.csv" -exec cp {} $O/bench_${name}_kernel_stats.csv \;
   find /tmp/st_$name -name "*domain_stats.csv" -exec cp {} $O/bench_${name}_domain_stats.csv \;
 done
