@@ -695,7 +695,7 @@ int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int b
         (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_kernel_name: bad argument");
     const TrunkPick pk = trunk_pick(filters, n_boards, flags & CRL_TRUNK_SPLIT);
-    snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d, %d>", filters, pk.nb,
+    snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d, %d, 0>", filters, pk.nb,
              (flags & CRL_TRUNK_BITPLANES) ? 1 : 0, pk.pair, pk.group, (flags & CRL_TRUNK_SPLIT) ? 1 : 0);
     return CRL_OK;
 }

@@ -221,6 +221,9 @@ class ChessModel(object):
     PROBE_TOL = 5e-4
     PROBE_POSITIONS = 256
     HYBRID_K = 2.0           # margin = HYBRID_K x max |log p_f16 - log p_f16x3| on the probe positions
+    HYBRID_MIN_BOARDS = 2048 # below, an S1 batch is simply evaluated in f16x3: the f16 pass + the fall-back launch
+                             # are two workgroup rounds, and a batch this small is one or two rounds of the split
+                             # kernel anyway (C2's 512 boards: hybrid 0.351 ms per step against 0.288 in f16x3)
     AUTO_STRICT = "hybrid"   # what "auto" runs when f16 is not within PROBE_TOL ("f16x3" = no S1 shortcut)
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
@@ -558,7 +561,7 @@ class ChessModel(object):
             if rc != 0:
                 raise _lib.HipLibraryError("%s failed (%d)" % (who, rc))
 
-        if self.precision == "hybrid" and val_out is None:
+        if self.precision == "hybrid" and val_out is None and planes.shape[0] >= self.HYBRID_MIN_BOARDS:
             # S1: the reply is an argmax over the legal labels.  Single-MFMA trunk for every board; the boards
             # whose two best legal moves are closer than the margin are listed on the device and evaluated again
             # by the split-precision kernels (a grid for the whole batch whose surplus workgroups exit at once);

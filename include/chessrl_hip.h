@@ -320,7 +320,7 @@ int  crl_heads_set_sliced_max(int boards);
 int  crl_trunk_set_small_batch(int enabled);
 
 /* Which kernel crl_trunk_forward_x launches for this filter count, batch and flags, written as
- * rocprofv3 prints it without namespace and argument list ("k_trunk_x16<128, 4, 1, 0, 1, 0, 0>"):
+ * rocprofv3 prints it without namespace and argument list ("k_trunk_x16<128, 4, 1, 0, 1, 0, 0, 0>"):
  * measurement tools look their profiles up by it instead of restating the dispatch rule.  No
  * reference counterpart (model.py:31-63 builds one Keras graph). */
 int  crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int buf_len);

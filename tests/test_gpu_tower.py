@@ -197,6 +197,7 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
     out = {}
     for mode in ("f16x3", "hybrid", "f16"):
         model = ChessModel(weights=sharp, precision=mode)
+        model.HYBRID_MIN_BOARDS = 0                                  # (batches this small would run plain f16x3)
         eng = LockstepEngine(model, G, sims)
         eng.reset()
         for ply in range(int(target.max())):                         # the same random playouts for every mode
