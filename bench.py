@@ -586,6 +586,7 @@ def main():
         strictest = order[agree_max(dist, order.index(model.precision), rdev)]
         if strictest != model.precision:
             model.set_precision(strictest)
+    probe_at_load = dict(model.precision_probe) if getattr(model, "precision_probe", None) else None
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
                          device=local, use_graph=not a.no_graph, max_plies=max_plies,
@@ -785,7 +786,7 @@ def main():
                        "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
                        "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",
                        "tower_precision": getattr(model, "precision", a.dtype),
-                       "tower_precision_requested": a.precision, "tower_precision_probe": model.precision_probe,
+                       "tower_precision_requested": a.precision, "tower_precision_probe": probe_at_load,
                        "tower_precision_why": ("the mode first timed missed the 1e-3 bar against the fp32 oracle on these "
                                                "weights (tower_error_vs_fp32.first_timed_mode): timed again in " + model.precision if retime
                                                else ("asked for by --precision" if a.precision != "auto" else
