@@ -379,7 +379,7 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
         assert stats["dma_transfers"] > 400 and stats["lds_reads"] > 3000 and stats["epochs"] >= 30, l
 
 
-@pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0", "64,2,1,0,0,0,0", "64,4,1,0,0,1,0", "128,2,1,0,1,0,1"])
+@pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0,0", "64,2,1,0,0,0,0,0", "64,4,1,0,0,1,0,0", "128,2,1,0,1,0,1,0"])
 def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     """Negative controls of the emulation: loosening a steady-state ``vmcnt`` wait by one, removing a tile
     barrier and loosening a fragment ``lgkmcnt`` wait by one must each be reported (pair ring, plain ring,
