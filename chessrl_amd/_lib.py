@@ -55,6 +55,7 @@ SYMBOLS = [
     "crl_trunk_forward_bitplanes", "crl_trunk_forward_x", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
     "crl_heads_forward_legal", "crl_heads_forward_legal_raw", "crl_heads_raw_supported", "crl_heads_set_sliced_max",
     "crl_set_policy_stats", "crl_abi_version", "crl_source_hash", "crl_reply_margin", "crl_trunk_forward_indexed",
+    "crl_end_move_fetch", "crl_advance_fetch",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
 
@@ -63,7 +64,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
+ABI_VERSION = 6          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
 _HASH_MARK = b"CRL_SRC_HASH="
 
 
@@ -196,6 +197,8 @@ def lib():
     L.crl_root_children.argtypes = [vp] * 8
     L.crl_advance.argtypes = [vp, vp, vp, vp]
     L.crl_counters.argtypes = [vp, vp]
+    L.crl_end_move_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.crl_advance_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -415,6 +418,25 @@ class Context(object):
         am = np.zeros(self.G, np.uint16)
         self._ck(self._L.crl_advance(self._h, _ptr(c), _ptr(bm), _ptr(am)), "crl_advance")
         return bm, am
+
+    def end_move_fetch(self, dev_policy_s2, dev_value_s2):
+        """sim_backup + root children (nchild, visits, root_visits) + plies in one synchronising call."""
+        G = self.G
+        nchild, root_visits, plies = (np.zeros(G, np.int32) for _ in range(3))
+        visits = np.zeros((G, MAX_MOVES), np.int32)
+        self._ck(self._L.crl_end_move_fetch(self._h, ctypes.c_void_p(dev_policy_s2), ctypes.c_void_p(dev_value_s2),
+                                            _ptr(nchild), _ptr(visits), _ptr(root_visits), _ptr(plies)),
+                 "crl_end_move_fetch")
+        return nchild, visits, root_visits, plies
+
+    def advance_fetch(self, chosen):
+        """advance + results + legal-move counts of the next roots in one synchronising call."""
+        c = np.ascontiguousarray(chosen, dtype=np.int32)
+        assert c.shape == (self.G,)
+        res = np.zeros(self.G, np.int8)
+        counts = np.zeros(self.G, np.int32)
+        self._ck(self._L.crl_advance_fetch(self._h, _ptr(c), None, None, _ptr(res), _ptr(counts)), "crl_advance_fetch")
+        return res, counts
 
     def counters(self):
         c = np.zeros(6, dtype=np.uint64)

@@ -533,6 +533,45 @@ int crl_advance(crl_ctx *ctx, const int32_t *chosen, uint16_t *bm, uint16_t *am)
     return check_dev_error(ctx);
 }
 
+// ---- the move boundary in two synchronising calls (SelfPlayRunner.end_move) --------------------------------
+int crl_end_move_fetch(crl_ctx *ctx, const void *dev_policy_s2_f32, const void *dev_value_s2_f32, int32_t *nchild,
+                       int32_t *visits, int32_t *root_visits, int32_t *plies)
+{
+    if (!ctx || !dev_policy_s2_f32 || !dev_value_s2_f32 || !nchild || !visits || !root_visits || !plies)
+        return fail(ctx, CRL_ERR_ARG, "crl_end_move_fetch: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->W, R = G * MAX_MOVES;
+    hipStream_t s = ctx->stream;
+    LAUNCH(ctx, k_backup, ctx->d, (const float *)dev_policy_s2_f32, (const float *)dev_value_s2_f32);
+    LAUNCH(ctx, k_root_children, ctx->d, ctx->t_i32b, ctx->t_i32a, ctx->t_f64, ctx->t_f32, ctx->t_moves,
+           ctx->t_moves2, ctx->t_i32c);
+    HIP_TRY(ctx, hipMemcpyAsync(nchild, ctx->t_i32b, G * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(visits, ctx->t_i32a, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(root_visits, ctx->t_i32c, G * 4, hipMemcpyDeviceToHost, s));
+    // (the copies above are queued behind k_root_children; the staging arrays are free again for the scalars)
+    LAUNCH(ctx, k_game_scalars, ctx->d, ctx->t_i32b, (int8_t *)ctx->t_u8);
+    HIP_TRY(ctx, hipMemcpyAsync(plies, ctx->t_i32b, G * 4, hipMemcpyDeviceToHost, s));
+    return check_dev_error(ctx);
+}
+
+int crl_advance_fetch(crl_ctx *ctx, const int32_t *chosen, uint16_t *bm, uint16_t *am, int8_t *results,
+                      int32_t *legal_counts)
+{
+    if (!ctx || !chosen || !results || !legal_counts) return fail(ctx, CRL_ERR_ARG, "crl_advance_fetch: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t G = ctx->W;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->t_i32b, chosen, G * 4, hipMemcpyHostToDevice, s));
+    LAUNCH(ctx, k_advance, ctx->d, (const int32_t *)ctx->t_i32b, ctx->t_u16a, ctx->t_u16b);
+    if (bm) HIP_TRY(ctx, hipMemcpyAsync(bm, ctx->t_u16a, G * 2, hipMemcpyDeviceToHost, s));
+    if (am) HIP_TRY(ctx, hipMemcpyAsync(am, ctx->t_u16b, G * 2, hipMemcpyDeviceToHost, s));
+    LAUNCH(ctx, k_game_scalars, ctx->d, ctx->t_i32c, (int8_t *)ctx->t_u8);
+    HIP_TRY(ctx, hipMemcpyAsync(results, ctx->t_u8, G, hipMemcpyDeviceToHost, s));
+    LAUNCH(ctx, k_legal_moves, ctx->d, ctx->t_moves, ctx->t_i32b);
+    HIP_TRY(ctx, hipMemcpyAsync(legal_counts, ctx->t_i32b, G * 4, hipMemcpyDeviceToHost, s));
+    return check_dev_error(ctx);
+}
+
 int crl_counters(crl_ctx *ctx, uint64_t *out6)
 {
     if (!ctx || !out6) return CRL_ERR_ARG;

@@ -165,17 +165,17 @@ class SelfPlayRunner(object):
         """Last backprop, compute_policy + argmax on the host, the two pushes, harvest of
         finished games and refill of their slots."""
         eng = self.engine
-        eng.ctx.sim_backup(eng.pri_s2.data_ptr(), eng.val_s2.data_ptr())
-        rc = eng.ctx.root_children(("nchild", "visits", "root_visits"))
-        _, plies, _ = eng.ctx.records(with_moves=False)
-        nchild = np.where(self.game_id >= 0, rc["nchild"], 0)
+        # (backup + root statistics + plies: one synchronising call; advance + results + the next roots' legal
+        # counts: another -- five calls of ~70 us each before)
+        nchild_all, visits, root_visits, plies = eng.ctx.end_move_fetch(eng.pri_s2.data_ptr(), eng.val_s2.data_ptr())
+        nchild = np.where(self.game_id >= 0, nchild_all, 0)
         rows = self._noise_rows if self._sims_in_move == self.sims else None    # (a shortened move draws here)
         if rows is None and self._noise_rows is not None:
             # shortened AFTER the draw ahead: rewind every stream to where it stood, so that the draw below
             # is the one the reference would make (one dirichlet per move and game, in stream order)
             for g, st in self._noise_states.items():
                 self.rngs[g].bit_generator.state = st
-        chosen = choose_children(rc["visits"], nchild, rc["root_visits"], plies, noise=self.noise,
+        chosen = choose_children(visits, nchild, root_visits, plies, noise=self.noise,
                                  rngs=self.rngs, noise_rows=rows)
         self._noise_rows = None
         # A record that cannot take another full move (our move + the reply) has reached the engine's
@@ -186,11 +186,10 @@ class SelfPlayRunner(object):
         full = self.active() & (chosen >= 0) & (np.asarray(plies) + 2 > self.max_plies)
         chosen[full] = -1
         live = int((chosen >= 0).sum())
-        eng.advance(chosen)
+        res, next_legal = eng.ctx.advance_fetch(chosen)
         self.moves_played += live
         self.sims_run += live * self._sims_in_move
         self._sims_in_move = None
-        res = eng.ctx.results()
         done = ((res != _lib.RESULT_NONE) | full) & self.active()
         if done.any():
             moves, plies, res = eng.ctx.records()
@@ -207,8 +206,9 @@ class SelfPlayRunner(object):
                     self._round_done[r] = self._round_done.get(r, 0) + 1
             self._start(done)
             self._maybe_compact()
+            next_legal = None                               # slots were reset / moved: count again
         if self.noise:
-            self._root_legal = eng.ctx.legal_counts()       # the next roots (after pushes and refill)
+            self._root_legal = next_legal if next_legal is not None else eng.ctx.legal_counts()
         return live
 
     COMPACT_MIN = 64

@@ -69,7 +69,7 @@ typedef struct crl_ctx crl_ctx;
  * signature hands the GPU garbage pointers).  crl_source_hash(): sha256 over the sources (csrc/ + this
  * header + compiler flags) the library was built from, as chessrl_amd/_lib.py computes it; the string
  * is also findable in the file itself behind the marker "CRL_SRC_HASH=".  No reference counterpart. */
-#define CRL_ABI_VERSION 5
+#define CRL_ABI_VERSION 6
 int  crl_abi_version(void);
 const char *crl_source_hash(void);
 
@@ -193,6 +193,17 @@ int  crl_root_children(crl_ctx *ctx, int32_t *nchild /*G*/, int32_t *visits, dou
  * (children-order index, -1 = leave the slot alone).  bm/am (host, may be NULL) get our
  * move and the stored reply (CRL_NO_MOVE when the game ended on our move). */
 int  crl_advance(crl_ctx *ctx, const int32_t *chosen /*G*/, uint16_t *bm, uint16_t *am);
+/* The move boundary of the lockstep runner in TWO synchronising calls instead of five (a synchronisation costs
+ * ~70 us; at C2 a move is 13 ms).  crl_end_move_fetch = crl_sim_backup + crl_root_children(nchild, visits,
+ * root_visits) + len(Game) of every slot; the host then computes the policies (compute_policy, mctree.py:305-322)
+ * and crl_advance_fetch = crl_advance + crl_results + the number of legal moves of every NEXT root
+ * (len(get_legal_moves()): how many children the next search can have -- the runner draws its Dirichlet
+ * noise ahead with it).  Same kernels, same values as the single calls. */
+int  crl_end_move_fetch(crl_ctx *ctx, const void *dev_policy_s2_f32, const void *dev_value_s2_f32,
+                        int32_t *nchild /*G*/, int32_t *visits /*G x 256*/, int32_t *root_visits /*G*/,
+                        int32_t *plies /*G*/);
+int  crl_advance_fetch(crl_ctx *ctx, const int32_t *chosen /*G*/, uint16_t *bm, uint16_t *am,
+                       int8_t *results /*G*/, int32_t *legal_counts /*G*/);
 /* Device-side counters since crl_create: [0] simulations run, [1] nodes created,
  * [2] sum of selection depth (edges), [3] sum of legal moves over created nodes,
  * [4] tower evaluations consumed, [5] terminal leaves hit. */
