@@ -311,3 +311,52 @@ def test_ranks_keep_playing_while_rank_0_trains_in_the_background():
     # ... and rank 1 was never held: between two weight loads it ran simulations
     loads1 = got[1][2]
     assert len(loads1) >= 2 and all(b[2] > a[2] for a, b in zip(loads1, loads1[1:])), loads1
+
+
+def test_background_trainer_trains_in_order_and_surfaces_its_errors():
+    """BackgroundTrainer (one process): rounds are trained in submission order, each from the weights the
+    previous one produced; ``ready`` counts finished weight sets; an exception in the trainer thread is raised
+    at the next call instead of being lost with the thread."""
+    import time
+    import pytest
+    from chessrl_amd.selfplay import BackgroundTrainer
+    seen = []
+
+    def train(w, recs):
+        seen.append((float(w["w"][0]), list(recs)))
+        if recs == ["boom"]:
+            raise ValueError("bad round")
+        time.sleep(0.05)
+        return dict(w, w=w["w"] + len(recs)), [{"loss": 1.0}]
+
+    bg = BackgroundTrainer({"w": np.zeros(1)}, train_fn=train)
+    assert bg.ready() == 0
+    bg.submit(0, ["a", "b"])
+    bg.submit(1, ["c"])
+    bg.drain()
+    assert bg.ready() == 2 and float(bg.latest()[0]["w"][0]) == 3.0
+    assert seen == [(0.0, ["a", "b"]), (2.0, ["c"])] and [r for r, _, _ in bg.latest()[1]] == [0, 1]
+    bg.submit(2, ["boom"])
+    with pytest.raises(RuntimeError, match="background trainer failed"):
+        bg.drain()
+    with pytest.raises(RuntimeError):
+        bg.ready()
+
+
+def test_rolling_rounds_need_a_share_for_every_rank_and_count_empty_shares_as_complete():
+    """``round_size < world`` is refused (a rank without a share could never report a round complete); with
+    ``total_games`` not a multiple of the round size the last, partial round still counts, and a rank whose
+    share of it is empty reports it complete."""
+    import pytest
+    from chessrl_amd.selfplay import SelfPlayRunner
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = 3, 4, 2, 8
+    run._round_done, run.finished = {}, []
+    with pytest.raises(ValueError, match="smaller than the number of ranks"):
+        run.run_rolling(1)
+    run.rank, run.world, run.round_size, run.total_games = 1, 2, 4, 9          # rounds: 0-3, 4-7, 8 (rank 0 only)
+    assert [run._round_share(r) for r in range(3)] == [2, 2, 0]
+    run._round_done = {0: 2, 1: 2}
+    assert run.rounds_complete() == 3                                           # the empty share does not block
+    run._round_done = {0: 2, 1: 1}
+    assert run.rounds_complete() == 1
