@@ -288,10 +288,12 @@ def time_move_boundary(run):
     Host clock between two device synchronisations: the GPU is idle while the host works."""
     if run._sims_in_move is None:
         run.begin_move()
+    half = max(1, run.sims // 2)
     while run._sims_in_move < run.sims:
-        run.engine.step()
-        run._sims_in_move += 1
-        if run._sims_in_move == max(1, run.sims // 2):
+        k = (half if run._sims_in_move < half else run.sims) - run._sims_in_move
+        run.engine.run_steps(k)
+        run._sims_in_move += k
+        if run._sims_in_move == half:
             run._draw_noise_ahead()
     torch.cuda.synchronize()
     n0 = len(run.finished)
@@ -429,14 +431,13 @@ def timed_window(run, a, barrier):
         second_half = a.sims // 2 + 8
         start = second_half if a.steps <= a.sims - second_half - 1 else (a.sims - a.steps) // 2
         pre = max(0, start - a.warmup)
-    for _ in range(pre + a.warmup):
-        run.step()
+    run.steps(pre + a.warmup)
+    run.engine.prepare_graphs(a.steps)        # (nothing is captured inside the timed region)
     w = {"pre": pre, "window_start": run._sims_in_move or 0, "moves0": run.moves_played,
          "c0": run.engine.ctx.counters()}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run.step()
+    run.steps(a.steps)                        # K lockstep steps (the engine replays several steps per hipGraph launch)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -739,13 +740,12 @@ def main():
                 run.begin_move()                                # fresh trees (the profiled move is abandoned)
                 grow = min(max(8, run.sims // 4), run.sims // 2)
                 n3 = max(1, min(a.strict_steps, run.sims - grow - 1))
-                for _ in range(grow):
-                    eng.step()                                  # (re-captures the graph) to mid-move
+                eng.run_steps(grow)                             # (re-captures the graphs) to mid-move
+                eng.prepare_graphs(n3)
                 torch.cuda.synchronize()
                 cs0, fb0 = eng.ctx.counters()["sims"], model.fallback_boards()
                 ts = time.perf_counter()
-                for _ in range(n3):
-                    eng.step()
+                eng.run_steps(n3)
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - ts
                 run._sims_in_move = grow + n3
@@ -783,7 +783,8 @@ def main():
                                                            "random-init" if a.weights is None else
                                                            "TRAINED (%s)" % os.path.basename(a.weights)),
                        "games_per_gpu": G, "sims_per_move": a.sims, "tower": "%dx%d" % (B, F),
-                       "hipgraph": not a.no_graph, "fused_trunk_kernel": bool(model.fused),
+                       "hipgraph": not a.no_graph, "steps_per_hipgraph_launch": eng.STEPS_PER_GRAPH if not a.no_graph else None,
+                       "fused_trunk_kernel": bool(model.fused),
                        "policy_format": "legal priors [G,256]" if eng.legal_priors else "full [G,1968]",
                        "tower_precision": getattr(model, "precision", a.dtype),
                        "tower_precision_requested": a.precision, "tower_precision_probe": probe_at_load,

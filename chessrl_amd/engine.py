@@ -188,7 +188,8 @@ class LockstepEngine(object):
         self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
                       self.pri_s1, self.pri_s2)
         self.use_graph = use_graph
-        self._graph = None
+        self._graphs = {}                    # steps per graph -> captured hipGraph
+        self._graph_epoch = 0
         self._bind_stream()
 
     # ---- plumbing ---------------------------------------------------------------------
@@ -258,38 +259,81 @@ class LockstepEngine(object):
         self.phase_reply()
         self.phase_tower_s2()
 
-    def _capture(self):
+    # One hipGraph launch costs ~12 us between the last kernel of one graph and the first of the next (measured,
+    # tools/graph_unroll_probe.py): nothing at C3 (0.5 %), 9 % of a C2 step.  So the engine also keeps a graph of
+    # STEPS_PER_GRAPH consecutive steps and ``run_steps(n)`` replays that one for as long as n allows
+    # (C2: 133 -> 119 us per step, 3.84 -> 4.29 M simulations/s).
+    STEPS_PER_GRAPH = 8
+
+    def _capture(self, k=1):
         # warm the evaluator (library handles, autotuning, buffers it keeps between calls) outside of capture
         prepare = getattr(self.evaluator, "prepare", None)
         if prepare is not None:
             prepare(self.G)
-        side = torch.cuda.Stream(self.dev)
-        side.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                self.evaluator(self.planes_s1)
-        torch.cuda.current_stream(self.dev).wait_stream(side)
+        if not self._graphs:
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.evaluator(self.planes_s1)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
         # thread_local: another thread of this process (rank 0's background trainer) may allocate and launch
         # on its own stream while this thread captures
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._bind_stream()              # kernels must land on the capturing stream
-            self._step_body()
+            for _ in range(k):
+                self._step_body()
         self._bind_stream()
-        self._graph = g
+        self._graphs[k] = g
         self._graph_epoch = getattr(self.evaluator, "graph_epoch", 0)
+        return g
+
+    @property
+    def _graph(self):
+        """the one-step graph (None until captured); assigning None drops every captured graph"""
+        return self._graphs.get(1)
+
+    @_graph.setter
+    def _graph(self, value):
+        if value is not None:
+            raise ValueError("graphs are captured by the engine")
+        self._graphs = {}
+
+    def _graph_of(self, k):
+        # an evaluator whose kernel choice changed (ChessModel precision "auto" after new weights)
+        # says so through graph_epoch: the captured launches are stale, capture again
+        if self._graphs and self._graph_epoch != getattr(self.evaluator, "graph_epoch", 0):
+            self._graphs = {}
+        g = self._graphs.get(k)
+        return g if g is not None else self._capture(k)
+
+    def prepare_graphs(self, n_steps=None):
+        """Capture now what ``run_steps(n_steps)`` will replay (bench.py: no capture inside a timed region).
+        Capturing launches nothing: the search state is untouched."""
+        if self.use_graph:
+            if n_steps is None or n_steps >= self.STEPS_PER_GRAPH > 1:
+                self._graph_of(self.STEPS_PER_GRAPH)
+            self._graph_of(1)
+
+    def run_steps(self, n):
+        """``n`` simulations for every game (enqueue only, no host sync)."""
+        if not self.use_graph:
+            for _ in range(n):
+                self._step_body()
+            return
+        K = self.STEPS_PER_GRAPH
+        while K > 1 and n >= K:
+            self._graph_of(K).replay()
+            n -= K
+        while n > 0:
+            self._graph_of(1).replay()
+            n -= 1
 
     def step(self):
         """One simulation for every game (enqueue only, no host sync)."""
-        if self.use_graph:
-            # an evaluator whose kernel choice changed (ChessModel precision "auto" after new weights)
-            # says so through graph_epoch: the captured launches are stale, capture again
-            if self._graph is None or self._graph_epoch != getattr(self.evaluator, "graph_epoch", 0):
-                self._capture()
-            self._graph.replay()
-        else:
-            self._step_body()
+        self.run_steps(1)
 
     # ---- SelfPlayTree surface -------------------------------------------------------------
     def search_begin(self):
@@ -304,8 +348,7 @@ class LockstepEngine(object):
         if n_sims > self.max_sims:
             raise ValueError("n_sims exceeds the max_sims this engine was created with")
         self.search_begin()
-        for _ in range(n_sims):
-            self.step()
+        self.run_steps(n_sims)
         self.ctx.sim_backup(self.pri_s2.data_ptr(), self.val_s2.data_ptr())
 
     def root_children(self):

@@ -129,16 +129,30 @@ class SelfPlayRunner(object):
     def step(self):
         """One lockstep simulation for every game; runs the move boundary when the budget of
         ``sims`` per move is reached.  Returns True when a move boundary was crossed."""
-        if self._sims_in_move is None:
-            self.begin_move()
-        self.engine.step()
-        self._sims_in_move += 1
-        if self._sims_in_move == max(1, self.sims // 2):
-            self._draw_noise_ahead()
-        if self._sims_in_move >= self.sims:
-            self.end_move()
-            return True
-        return False
+        return self.steps(1) > 0
+
+    def steps(self, n):
+        """``n`` lockstep simulations for every game, move boundaries included wherever a move's budget of
+        ``sims`` completes; returns the number of boundaries crossed.  The same games as ``n`` calls of
+        ``step()``: the steps in between are handed to the engine in one piece (``run_steps``: several steps per
+        hipGraph launch), cut where the runner has something to do -- the noise draw half-way through a move,
+        the boundary."""
+        crossed = 0
+        half = max(1, self.sims // 2)
+        while n > 0:
+            if self._sims_in_move is None:
+                self.begin_move()
+            stop = half if self._sims_in_move < half else self.sims
+            k = min(n, stop - self._sims_in_move)
+            self.engine.run_steps(k)
+            self._sims_in_move += k
+            n -= k
+            if self._sims_in_move == half:
+                self._draw_noise_ahead()
+            if self._sims_in_move >= self.sims:
+                self.end_move()
+                crossed += 1
+        return crossed
 
     def _draw_noise_ahead(self):
         """The Dirichlet draws of this move's ``compute_policy`` (mctree.py:317-320), made on the
@@ -249,8 +263,7 @@ class SelfPlayRunner(object):
     def play_move(self):
         """search_move + the two pushes for every running game (``sims`` lockstep steps)."""
         self.begin_move()
-        for _ in range(self.sims):
-            self.engine.step()
+        self.engine.run_steps(self.sims)
         self._sims_in_move = self.sims
         self._draw_noise_ahead()                 # the steps are enqueued; the GPU is busy with them
         return self.end_move() * self.sims

@@ -110,11 +110,12 @@ def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
     eng = LockstepEngine(model, n_games=8, max_sims=8)
     eng.reset()
     eng.search(8)
-    first = eng._graph
+    first = dict(eng._graphs)
+    assert first
     model.load_dict(sharp)                                          # in place, under the captured graph
     assert model.precision == "hybrid" and model.graph_epoch == 1 and model.reply_margin > 0
     eng.search(8)
-    assert eng._graph is not first                                  # re-captured with the split kernels
+    assert eng._graphs and all(eng._graphs.get(k) is not g for k, g in first.items())   # re-captured with the split kernels
     rc = eng.root_children()
     assert (rc["root_visits"] == 9).all()
     eng.close()
