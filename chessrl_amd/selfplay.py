@@ -61,12 +61,28 @@ def game_color(seed, game_id):
     return random.Random((seed << 20) ^ game_id).random() >= 0.5
 
 
+_numpy_warm = False
+
+
+def _warm_numpy():
+    """The first large numpy multiply / add of a process that has imported torch costs ~0.2 s (measured: 186 ms
+    for a 4096 x 20 float64 ``0.75 * x + y`` against 0.2 ms afterwards); it used to land in the first full move
+    boundary (``choose_children``), where the GPU waits.  Paid here, once, while the runner is being built."""
+    global _numpy_warm
+    if not _numpy_warm:
+        x = np.ones((4096, 32))
+        (1 - 0.25) * x + x
+        np.argmax(np.where(x > 0, x, -np.inf), axis=1)
+        _numpy_warm = True
+
+
 class SelfPlayRunner(object):
     """Lockstep self-play of ``n_parallel`` games on one GPU (one rank of ``world``)."""
 
     def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
                  max_plies=4096, numpy_promotion="auto", use_graph=True, total_games=None,
                  compact=True, round_size=None):
+        _warm_numpy()
         self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
                                      numpy_promotion=numpy_promotion, use_graph=use_graph)
         self.G, self.sims, self.seed, self.noise = n_parallel, sims, seed, noise
