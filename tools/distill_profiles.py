@@ -25,7 +25,8 @@ def per_kernel(path, last=None):
 
 passes, summary = [], {}
 shapes = {"trunk128": "4096 boards, 10 blocks x 128 filters", "trunk256": "4096 boards, 20 blocks x 256 filters",
-          "trunk64": "512 boards, 6 blocks x 64 filters", "trunk128x3": "4096 boards, 10 blocks x 128 filters"}
+          "trunk64": "512 boards, 6 blocks x 64 filters", "trunk128x3": "4096 boards, 10 blocks x 128 filters",
+          "trunk256x3": "4096 boards, 20 blocks x 256 filters"}
 for tag, shape in shapes.items():
     if not os.path.exists(os.path.join(SRC, tag + "_FETCH_SIZE.csv")):
         continue

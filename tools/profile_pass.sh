@@ -22,6 +22,8 @@ pmc trunk64 FETCH_SIZE python3 $R/tools/trunk_once.py 6 64 512
 pmc trunk64 WRITE_SIZE python3 $R/tools/trunk_once.py 6 64 512
 pmc trunk128x3 FETCH_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
 pmc trunk128x3 WRITE_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
+pmc trunk256x3 FETCH_SIZE python3 $R/tools/trunk_once.py 20 256 4096 f16x3
+pmc trunk256x3 WRITE_SIZE python3 $R/tools/trunk_once.py 20 256 4096 f16x3
 pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 1
 pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
 pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0
