@@ -230,7 +230,7 @@ def _async_train_worker(rank, world, port, q):
     from chessrl_amd import records
     from chessrl_amd.selfplay import BackgroundTrainer, SelfPlayRunner
     from chessrl_amd.train import broadcast_weights
-    N, R = 4, 3
+    N, R = 2 * world, 3
     run = SelfPlayRunner.__new__(SelfPlayRunner)
     run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
     run._round_done, run.finished = {}, []
@@ -264,7 +264,7 @@ def _async_train_worker(rank, world, port, q):
 
     def on_round(r, recs):
         allr = records.gather_records(recs, max_plies=8)
-        assert [x.game_id for x in allr] == list(range(N * r, N * r + N))
+        assert [x.game_id for x in allr] == list(range(N * r, N * r + N))      # every rank's share of the round
         if bg is not None:
             bg.submit(r, allr)
 
@@ -285,27 +285,31 @@ def _async_train_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ranks_keep_playing_while_rank_0_trains_in_the_background():
-    """Two gloo ranks, three rolling rounds, a trainer that takes 0.5 s per round on rank 0's thread:
-    rank 1's simulation counter (and rank 0's own) advances while the trainer works, every weight set
-    reaches both ranks through the news bit of the periodic all_reduce at the same sync index, and after
-    the final drain both hold the weights of the last round."""
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_keep_playing_while_rank_0_trains_in_the_background(world):
+    """Two (and eight: the node the scaling curve is run on) gloo ranks, three rolling rounds, a trainer that
+    takes 0.5 s per round on rank 0's thread: rank 1's simulation counter (and rank 0's own) advances while the
+    trainer works, every weight set reaches every rank through the news word of the periodic all_reduce at the
+    same sync index, and after the final drain all hold the weights of the last round."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37500 + (os.getpid() % 2000)
-    ps = [ctx.Process(target=_async_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 37500 + (os.getpid() % 2000) + world
+    ps = [ctx.Process(target=_async_train_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
-    got = {r: rest for r, *rest in (q.get(timeout=180) for _ in ps)}
+    got = {r: rest for r, *rest in (q.get(timeout=300) for _ in ps)}
     for p in ps:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    for rank in (0, 1):
+    for rank in range(world):
         done, w, loaded_at, _, sims = got[rank]
         assert done == 3 and w == 3.0                              # three rounds trained, last weights everywhere
         assert [k for k, _, _ in loaded_at] == sorted(k for k, _, _ in loaded_at) and loaded_at[-1][0] == 3
-    # same sync index on both ranks for every weight set (the collective inside on_news cannot dead-lock)
-    assert [(k, m) for k, m, _ in got[0][2]] == [(k, m) for k, m, _ in got[1][2]]
+        # same sync index on every rank for every weight set (the collective inside on_news cannot dead-lock)
+        assert [(k, m) for k, m, _ in loaded_at] == [(k, m) for k, m, _ in got[0][2]]
     # rank 0 itself played on while its trainer thread worked ...
     assert all(d > 0 for d in got[0][3][:2]), got[0][3]
     # ... and rank 1 was never held: between two weight loads it ran simulations
