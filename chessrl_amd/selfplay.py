@@ -323,7 +323,7 @@ class SelfPlayRunner(object):
         self.finished = [x for x in self.finished if not lo <= x.game_id < hi]
         return mine
 
-    def run_rolling(self, n_rounds, on_round=None, sync_every=8, poll=None, on_news=None):
+    def run_rolling(self, n_rounds, on_round=None, sync_every=8, poll=None, on_news=None, idle=None):
         """The reference's ``play N games, train, repeat`` (selfplay.py:142-163) without its tail: a
         lockstep batch that stops refilling when a round's last game has STARTED runs ever emptier
         until that game ends (game lengths spread 9...788 plies; measured: 28 % of a 4096-game
@@ -342,7 +342,10 @@ class SelfPlayRunner(object):
         rank's monotonic news counter (0 on ranks that never have any); the same all_reduce carries its
         maximum, and when that rises every rank calls ``on_news(k)`` at the SAME sync index (a
         collective inside it -- the weight broadcast -- is therefore safe) while nobody waited for it:
-        every rank kept playing until the news was there."""
+        every rank kept playing until the news was there.
+
+        ``idle(seconds_of_the_last_move)``: called after every move; a rank that shares its GPU with something
+        else (rank 0's background trainer) may pause there to hand it a share of the device."""
         if not self.round_size:
             raise ValueError("run_rolling needs round_size")
         if self.round_size < self.world:
@@ -351,8 +354,11 @@ class SelfPlayRunner(object):
         done, moves = 0, 0
         self._news_seen = getattr(self, "_news_seen", 0)
         while done < n_rounds:
+            t_move = time.perf_counter()
             if self.active().any():
                 self.play_move()
+            if idle is not None:
+                idle(time.perf_counter() - t_move)
             moves += 1                               # (a rank whose batch ran dry idles to the next sync)
             agreed, any_active, news = self._agree_rounds(moves, sync_every, done, poll)
             if on_news is not None and news > self._news_seen:
@@ -439,7 +445,7 @@ def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size
     return trainer.weights(), history
 
 
-TRAINER_STREAM_PRIORITY = -1      # the background trainer's HIP stream: high priority (see BackgroundTrainer._loop)
+TRAINER_STREAM_PRIORITY = 0       # the background trainer's HIP stream (a high priority, -1, was measured: no effect)
 
 
 class BackgroundTrainer(object):
@@ -472,6 +478,10 @@ class BackgroundTrainer(object):
         self._raise()
         self._q.put((rnd, list(records)))
 
+    def busy(self):
+        """A round is being trained or waiting to be."""
+        return self._q.unfinished_tasks > 0
+
     def ready(self):
         """Number of weight sets finished so far (monotonic)."""
         self._raise()
@@ -501,11 +511,12 @@ class BackgroundTrainer(object):
         if self._train_fn is None:
             import torch
             torch.cuda.set_device(self.device)
-            # HIGH priority: the trainer's kernels are thousands of small dependent launches; behind a lockstep
-            # batch whose trunk launches keep every CU busy for 1.1 ms at a time a normal-priority stream gets a
-            # CU only when a whole launch has drained (measured: 305 s for a round that takes 15 s alone); at
-            # high priority its kernels are dispatched as soon as any workgroup slot frees up.  Its total work is
-            # ~6 % of the self-play's (C3), which is what it then costs the self-play.
+            # The trainer's kernels are thousands of small dependent launches; beside a lockstep batch whose trunk
+            # launches fill every CU (all of its LDS and registers) for 1.1 ms at a time they are dispatched a
+            # few per trunk launch: 305 s for a round that takes 15 s alone (profiles/r04/
+            # rolling_probe_train_rounds1024.json), 23 s instead of 5.9 s beside a batch whose host syncs every 8
+            # steps, the same at stream priority -1 (tools/trainer_share_probe.py).  What gives it the device is
+            # the self-play's pause after a move (--trainer-share).
             stream = torch.cuda.Stream(self.device, priority=TRAINER_STREAM_PRIORITY)
         while True:
             item = self._q.get()
@@ -559,6 +570,12 @@ def main(argv=None):
                              "long games finish; a round is trained on as soon as its last game ends -- on "
                              "rank 0, in the background, while every rank keeps playing -- and the games "
                              "under way continue on the new weights once they are there")
+    parser.add_argument("--trainer-share", type=float, default=0.2,
+                        help="--rolling: fraction of rank 0's wall time its self-play leaves to the background trainer "
+                             "WHILE a round is waiting to be trained (a pause after every move; the trainer's thousands "
+                             "of small dependent kernels get almost nothing of the GPU beside a full lockstep batch: "
+                             "305 s for a round that takes 15 s alone).  C3 on one GPU needs ~0.2 to keep pace; 0 = "
+                             "self-play first, the trainer takes what is left")
     parser.add_argument("--max-plies", type=int, default=4096,
                         help="longest game record; a game still running there is handed over unfinished "
                              "(result None) and its slot refilled")
@@ -658,8 +675,16 @@ def main(argv=None):
                                 numpy_promotion=args.numpy_promotion)
         t0 = time.perf_counter()
         poll = (lambda: background.ready() if background is not None else 0) if not args.no_train else None
+        share = min(max(args.trainer_share, 0.0), 0.9)
+
+        def idle(move_seconds):
+            """rank 0, while its trainer has work: hand it ``share`` of the wall time (alone on the device it
+            trains ~4x faster than between the self-play's launches)"""
+            if background is not None and share > 0 and background.busy():
+                time.sleep(move_seconds * share / (1.0 - share))
+
         runner.run_rolling(args.rounds, on_round=after_round_rolling, poll=poll,
-                           on_news=new_weights if not args.no_train else None)
+                           on_news=new_weights if not args.no_train else None, idle=idle)
         dt = time.perf_counter() - t0
         log.info("rank %d: %d rolling rounds of %d games, %d sims in %.1fs (%.0f sims/s)", rank, args.rounds,
                  args.games, runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))

@@ -21,6 +21,7 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N = int(sys.argv[4]) if len(sys.argv) > 4 else G
 TRAIN = len(sys.argv) > 5 and sys.argv[5] == "train"
+SHARE = float(sys.argv[6]) if len(sys.argv) > 6 else 0.2      # of the wall time, to the trainer while it has work
 model = ChessModel(blocks=10, filters=128, precision="f16" if not TRAIN else "auto")
 run = SelfPlayRunner(model, G, S, seed=0, noise=True, total_games=R * N, round_size=N, max_plies=4096)
 t0 = time.time()
@@ -62,7 +63,8 @@ if TRAIN:
         loads.append({"weight_set": k, "at_s": time.time() - t0, "precision": model.precision})
         print(json.dumps(loads[-1]), flush=True)
 
-    done = run.run_rolling(R, on_round=on_round, poll=bg.ready, on_news=on_news)
+    idle = (lambda dt: time.sleep(dt * SHARE / (1.0 - SHARE)) if bg.busy() else None) if SHARE > 0 else None
+    done = run.run_rolling(R, on_round=on_round, poll=bg.ready, on_news=on_news, idle=idle)
 else:
     done = run.run_rolling(R, on_round=on_round)
 total = time.time() - t0
@@ -78,7 +80,7 @@ for k in range(0, int(tl[-1, 1]) - N + 1, max(1, N // 4)):
     tb = tl[np.searchsorted(tl[:, 1], k + N, side="left"), 0]
     windows.append({"from_game": k, "seconds": float(tb - ta), "games_per_hour": N / (tb - ta) * 3600.0})
 out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 %s" % model.precision, "round_size": N, "rounds": rounds,
-       "training_in_the_loop": TRAIN, "weight_loads": loads, "trainer": trainer if TRAIN else None,
+       "training_in_the_loop": TRAIN, "trainer_share": SHARE if TRAIN else None, "weight_loads": loads, "trainer": trainer if TRAIN else None,
        "seconds_until_last_round_trained": (time.time() - t0) if TRAIN else None,
        "rounds_done": done, "seconds_total": total, "games_total": int(tl[-1, 1]), "sims_run": run.sims_run,
        "sims_per_s_overall": run.sims_run / total, "games_per_hour_overall": tl[-1, 1] / total * 3600.0,
