@@ -323,7 +323,7 @@ class SelfPlayRunner(object):
         self.finished = [x for x in self.finished if not lo <= x.game_id < hi]
         return mine
 
-    def run_rolling(self, n_rounds, on_round=None, sync_every=8, poll=None, on_news=None, idle=None):
+    def run_rolling(self, n_rounds, on_round=None, sync_every=8, poll=None, on_news=None, idle=None, news="max"):
         """The reference's ``play N games, train, repeat`` (selfplay.py:142-163) without its tail: a
         lockstep batch that stops refilling when a round's last game has STARTED runs ever emptier
         until that game ends (game lengths spread 9...788 plies; measured: 28 % of a 4096-game
@@ -344,6 +344,9 @@ class SelfPlayRunner(object):
         collective inside it -- the weight broadcast -- is therefore safe) while nobody waited for it:
         every rank kept playing until the news was there.
 
+        ``news="min"``: the counter every rank has REACHED (each rank has a trainer of its own, data-parallel
+        training) instead of the highest any rank has.
+
         ``idle(seconds_of_the_last_move)``: called after every move; a rank that shares its GPU with something
         else (rank 0's background trainer) may pause there to hand it a share of the device."""
         if not self.round_size:
@@ -360,10 +363,10 @@ class SelfPlayRunner(object):
             if idle is not None:
                 idle(time.perf_counter() - t_move)
             moves += 1                               # (a rank whose batch ran dry idles to the next sync)
-            agreed, any_active, news = self._agree_rounds(moves, sync_every, done, poll)
-            if on_news is not None and news > self._news_seen:
-                self._news_seen = news
-                on_news(news)
+            agreed, any_active, seen = self._agree_rounds(moves, sync_every, done, poll, news)
+            if on_news is not None and seen > self._news_seen:
+                self._news_seen = seen
+                on_news(seen)
             while done < min(agreed, n_rounds):
                 recs = self.take_round(done)
                 if on_round is not None:
@@ -375,18 +378,18 @@ class SelfPlayRunner(object):
             raise RuntimeError("run_rolling ended with %d rounds handed over of %d complete" % (done, self.rounds_complete()))
         return done
 
-    def sync_news(self, poll, on_news):
+    def sync_news(self, poll, on_news, news="max"):
         """One agreement on the news counter outside the move loop (after the last round: the trainer's
         remaining weight sets).  Every rank calls it; returns the agreed counter."""
-        _, _, news = self._agree_rounds(0, 1, 0, poll)
-        if on_news is not None and news > getattr(self, "_news_seen", 0):
-            self._news_seen = news
-            on_news(news)
-        return news
+        _, _, seen = self._agree_rounds(0, 1, 0, poll, news)
+        if on_news is not None and seen > getattr(self, "_news_seen", 0):
+            self._news_seen = seen
+            on_news(seen)
+        return seen
 
-    def _agree_rounds(self, moves, sync_every, done, poll=None):
-        """(rounds complete on EVERY rank, is any rank still playing, highest news counter of any rank)
-        -- as of the last sync."""
+    def _agree_rounds(self, moves, sync_every, done, poll=None, news="max"):
+        """(rounds complete on EVERY rank, is any rank still playing, news counter: the highest of any rank, or
+        with news="min" the one every rank has reached) -- as of the last sync."""
         local, active = self.rounds_complete(), bool(self.active().any())
         mine = int(poll()) if poll is not None else 0
         if self.world == 1:
@@ -396,9 +399,9 @@ class SelfPlayRunner(object):
         import torch
         import torch.distributed as dist
         dev = self.engine.dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([local, -int(active), -mine], dtype=torch.int64, device=dev)
+        t = torch.tensor([local, -int(active), -mine if news == "max" else mine], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return int(t[0].item()), bool(t[1].item() < 0), int(-t[2].item())
+        return int(t[0].item()), bool(t[1].item() < 0), int(-t[2].item() if news == "max" else t[2].item())
 
     def close(self):
         self.engine.close()
@@ -421,16 +424,17 @@ def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=
     return history
 
 
-def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size=1):
+def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size=1, group=None):
     """The arithmetic of ``train_model_job`` without a ``ChessModel``: (trained weight dict, history) from
     a weight dict and the recorded games, on whatever stream is current -- what the background trainer runs
-    beside the self-play that keeps using the model."""
+    beside the self-play that keeps using the model.  With ``group`` (a process group of trainer threads, one
+    per rank) the ranks train together on their own games (``train.fit_data_parallel``)."""
     from .dataset import DatasetGame
     from .netencoder import DataGameSequence
     from .train import Trainer
     data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0
                               and not getattr(r, "truncated", False)])
-    if len(data_train) == 0:
+    if len(data_train) == 0 and group is None:
         return weights, None
     gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
     trainer = Trainer(weights, device)              # a fresh optimizer per round, as in the reference
@@ -461,12 +465,14 @@ class BackgroundTrainer(object):
     are only ever rewritten by the main thread at a move boundary (``ChessModel.load_dict``), never here.
     ``train_fn(weights, records) -> (weights, history)`` defaults to ``train_weights`` on ``device``."""
 
-    def __init__(self, weights, device=None, model_path=None, model_dir=None, train_fn=None):
+    def __init__(self, weights, device=None, model_path=None, model_dir=None, train_fn=None, group=None):
         import queue
         import threading
         self._q = queue.Queue()
         self._lock = threading.Lock()
         self._weights = weights
+        self._sets = {}                      # finished count -> that weight set (until taken)
+        self.group = group                   # data-parallel: the trainer threads' own process group
         self._done = []                      # (round, seconds, last history entry)
         self.error = None
         self.device, self.model_path, self.model_dir = device, model_path, model_dir
@@ -491,6 +497,16 @@ class BackgroundTrainer(object):
     def latest(self):
         with self._lock:
             return self._weights, list(self._done)
+
+    def take(self, k):
+        """Weight set number ``k`` (1 = after the first trained round); older sets are dropped.  In the
+        data-parallel mode every rank loads the SAME set at the same sync index, whatever its own trainer has
+        finished since."""
+        with self._lock:
+            w = self._sets[k]
+            for old in [c for c in self._sets if c <= k]:
+                del self._sets[old]
+            return w
 
     def drain(self):
         """Block until every submitted round is trained."""
@@ -530,7 +546,7 @@ class BackgroundTrainer(object):
                 else:
                     import torch
                     with torch.cuda.stream(stream):
-                        new, hist = train_weights(self._weights, records, self.device, self.model_dir)
+                        new, hist = train_weights(self._weights, records, self.device, self.model_dir, group=self.group)
                     stream.synchronize()
                 if self.model_path is not None:
                     if str(self.model_path).endswith((".h5", ".hdf5")):
@@ -541,6 +557,8 @@ class BackgroundTrainer(object):
                 with self._lock:
                     self._weights = new
                     self._done.append((rnd, time.perf_counter() - t0, hist[-1] if hist else None))
+                    if self.group is not None:
+                        self._sets[len(self._done)] = new
                 log.info("trainer: round %d trained on %d games in %.1fs", rnd, len(records), time.perf_counter() - t0)
             except BaseException as e:                    # surfaces at the next submit / ready / drain
                 self.error = e
@@ -570,6 +588,12 @@ def main(argv=None):
                              "long games finish; a round is trained on as soon as its last game ends -- on "
                              "rank 0, in the background, while every rank keeps playing -- and the games "
                              "under way continue on the new weights once they are there")
+    parser.add_argument("--train-mode", choices=["rank0", "dp"], default="rank0",
+                        help="--rolling on several GPUs: 'rank0' = rank 0 trains on every rank's games, one Adam step "
+                             "per game in the reference's order (selfplay.py:98-108; one GPU trains ~25 k positions/s, "
+                             "eight produce ~35 k/s at C3: the weights lag); 'dp' = every rank trains on ITS games, "
+                             "gradients averaged over RCCL, one Adam step per <ranks> games -- not the reference's "
+                             "arithmetic, but a trainer that scales with the GPUs")
     parser.add_argument("--trainer-share", type=float, default=0.2,
                         help="--rolling: fraction of rank 0's wall time its self-play leaves to the background trainer "
                              "WHILE a round is waiting to be trained (a pause after every move; the trainer's thousands "
@@ -620,8 +644,13 @@ def main(argv=None):
     parallel = args.parallel or min(per_rank, 4096)
     allrecs = []
     max_plies = args.max_plies
-    background = (BackgroundTrainer(model.weights, "cuda:%d" % local, path, args.model_dir)
-                  if (args.rolling and not args.no_train and rank == 0) else None)
+    dp = args.train_mode == "dp" and world > 1 and args.rolling and not args.no_train
+    # (data-parallel: the trainer THREADS of all ranks talk over a process group of their own -- a communicator
+    # serves one thread at a time, and the main threads keep using the default group)
+    train_group = dist.new_group(backend=dist.get_backend(), timeout=datetime.timedelta(minutes=args.dist_timeout_min)) if dp else None
+    background = (BackgroundTrainer(model.weights, "cuda:%d" % local, path if rank == 0 else None, args.model_dir if rank == 0 else None,
+                                    group=train_group)
+                  if (args.rolling and not args.no_train and (rank == 0 or dp)) else None)
 
     def store(rnd, recs):
         """Gather the round's records (RCCL) and store them (rank 0)."""
@@ -654,15 +683,18 @@ def main(argv=None):
         """Rolling rounds: gather, store, hand the round to rank 0's background trainer and play on."""
         newrecs = store(rnd, recs)
         if background is not None:
-            background.submit(rnd, newrecs)
+            background.submit(rnd, recs if dp else newrecs)        # dp: every rank trains on its own share
 
     def new_weights(k):
         """Every rank, at the same sync index: rank 0's newest trained weights into the inference tensors
         (one flat broadcast; in place, so the captured hipGraph stays valid)."""
-        w = background.latest()[0] if background is not None else model.weights
-        if world > 1:
-            from .train import broadcast_weights
-            w = broadcast_weights(w, "cuda:%d" % local, src=0)
+        if dp:
+            w = background.take(k)           # every rank's trainer produced the same set k
+        else:
+            w = background.latest()[0] if background is not None else model.weights
+            if world > 1:
+                from .train import broadcast_weights
+                w = broadcast_weights(w, "cuda:%d" % local, src=0)
         model.load_dict(w)
         log.info("rank %d: weight set %d loaded", rank, k)
 
@@ -684,14 +716,14 @@ def main(argv=None):
                 time.sleep(move_seconds * share / (1.0 - share))
 
         runner.run_rolling(args.rounds, on_round=after_round_rolling, poll=poll,
-                           on_news=new_weights if not args.no_train else None, idle=idle)
+                           on_news=new_weights if not args.no_train else None, idle=idle, news="min" if dp else "max")
         dt = time.perf_counter() - t0
         log.info("rank %d: %d rolling rounds of %d games, %d sims in %.1fs (%.0f sims/s)", rank, args.rounds,
                  args.games, runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))
         if not args.no_train:
             if background is not None:
                 background.drain()                    # the last rounds' training (the other ranks wait in sync_news)
-            runner.sync_news(poll, new_weights)
+            runner.sync_news(poll, new_weights, news="min" if dp else "max")
             if background is not None:
                 background.close()
         runner.close()
@@ -708,6 +740,9 @@ def main(argv=None):
                      runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))
             runner.close()
             after_round(rnd, recs)
+    import hashlib
+    digest = hashlib.sha1(b"".join(np.ascontiguousarray(model.weights[k]).tobytes() for k in sorted(model.weights))).hexdigest()
+    log.info("rank %d: weights at the end %s (%s)", rank, digest[:16], model.precision)
     if world > 1:
         dist.destroy_process_group()
 

@@ -279,15 +279,21 @@ class Trainer(object):
 
     def train_on_batch(self, planes, move_index, result):
         """One optimizer step; returns dict(loss, policy_loss, value_loss, reg_loss, accuracy)."""
+        logs = self.backward_on_batch(planes, move_index, result)
+        self.opt.step()
+        return {k: v.item() for k, v in logs.items()}
+
+    def backward_on_batch(self, planes, move_index, result):
+        """Forward + backward of one batch: the gradients are left on the parameters, no step is taken (the
+        data-parallel trainer averages them over the ranks first).  Returns the metrics as device scalars."""
         self.net.train()
         self.opt.zero_grad()
         policy, value = self.net(planes)
         total, cce, mse, reg = keras_losses(policy, value, move_index, result, self.net.regularized())
         total.backward()
-        self.opt.step()
         acc = (policy.argmax(dim=-1) == move_index).float().mean()
-        return {"loss": total.item(), "policy_out_loss": cce.item(), "value_out_loss": mse.item(),
-                "reg_loss": reg.item(), "policy_out_accuracy": acc.item()}
+        return {"loss": total.detach(), "policy_out_loss": cce.detach(), "value_out_loss": mse.detach(),
+                "reg_loss": reg.detach(), "policy_out_accuracy": acc}
 
     @torch.no_grad()
     def evaluate(self, planes, move_index, result):
@@ -321,6 +327,73 @@ class Trainer(object):
 
     def weights(self):
         return self.net.to_keras_dict()
+
+
+def fit_data_parallel(trainer, generator, group=None, epochs=1, log=None):
+    """One ``fit_generator`` pass with the ranks of ``group`` training TOGETHER: every rank holds the same
+    weights and its own games; step i takes one game per rank, the gradients are averaged over the ranks that
+    still have a game (one flat all_reduce over RCCL), and every rank applies the same Adam step.  The
+    BatchNorm moving statistics, which every rank updates from its own batches, are averaged at the end.
+    NOT the reference's arithmetic: its ``fit_generator`` takes one Adam step per game (model.py:83-99), this
+    takes one per ``world`` games -- the price of a trainer whose throughput grows with the number of GPUs.
+    Every rank must call it with the same ``epochs``; returns this rank's history."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cpu_group = dist.get_backend(group) != "nccl"
+    dev = trainer.device
+    params = trainer.opt.params
+    sizes = [p.numel() for p in params]
+    history = []
+    for epoch in range(epochs):
+        order = np.random.permutation(len(generator))
+        n = torch.tensor([len(order)], dtype=torch.int64, device="cpu" if cpu_group else dev)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+        logs = []
+        for i in range(int(n.item())):
+            have = i < len(order)
+            if have:
+                planes, move_index, result = generator.device_batch(int(order[i]), dev)
+                have = planes.shape[0] > 0
+            if have:
+                logs.append(trainer.backward_on_batch(planes, move_index, result))
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+            else:
+                grads = [torch.zeros_like(p) for p in params]
+            flat = torch.cat([g.reshape(-1) for g in grads] + [torch.full((1,), float(have), device=dev)])
+            if cpu_group:
+                host = flat.cpu()
+                dist.all_reduce(host, group=group)
+                flat = host.to(dev)
+            else:
+                dist.all_reduce(flat, group=group)
+            flat = flat[:-1] / flat[-1].clamp(min=1.0)
+            off = 0
+            for p, k in zip(params, sizes):
+                p.grad = flat[off:off + k].view_as(p)
+                off += k
+            trainer.opt.step()
+        # BatchNorm moving statistics: the mean over the ranks
+        bufs = [b for m in trainer.net.modules() if isinstance(m, nn.BatchNorm2d) for b in (m.running_mean, m.running_var)]
+        flatb = torch.cat([b.reshape(-1) for b in bufs])
+        if cpu_group:
+            host = flatb.cpu()
+            dist.all_reduce(host, group=group)
+            flatb = host.to(dev)
+        else:
+            dist.all_reduce(flatb, group=group)
+        flatb /= world
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flatb[off:off + b.numel()].view_as(b))
+                off += b.numel()
+        summary = {k: float(np.mean([l[k].item() for l in logs])) for k in logs[0]} if logs else {}
+        summary["epoch"] = epoch
+        summary["ranks"] = world
+        history.append(summary)
+        if log is not None:
+            log(summary)
+    return history
 
 
 def broadcast_weights(weights, device, src=0):

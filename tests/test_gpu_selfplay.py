@@ -499,6 +499,35 @@ def test_rolling_rounds_play_the_same_games_and_hand_rounds_over_in_order():
     c.close()
 
 
+def test_cli_rolling_rounds_with_data_parallel_training_end_on_the_same_weights(tmp_path):
+    """``--rolling --train-mode dp`` on two ranks (torchrun x 2, gloo, both on this GPU): every rank's background
+    trainer trains on ITS games, the gradients are averaged over the trainer threads' own process group, one
+    Adam step per two games; both ranks load every weight set at the same sync index and end on bit-identical
+    weights without a broadcast."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "models")
+    env = dict(os.environ, CRL_DIST_BACKEND="gloo", CRL_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29890 + os.getpid() % 40),
+           "-m", "chessrl_amd.selfplay", d, "--games", "6", "--sims", "4", "--blocks", "1", "--filters", "64",
+           "--rounds", "2", "--seed", "5", "--rolling", "--parallel", "4", "--train-mode", "dp"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = json.load(open(os.path.join(d, "gameplays.json")))
+    assert len(recs) == 12 and all(g["result"] in (1, -1, 0) for g in recs)
+    log = [json.loads(l) for l in open(os.path.join(d, "train_log.jsonl"))]
+    assert len(log) == 2 and all(e["ranks"] == 2 and np.isfinite(e["loss"]) for e in log)
+    ends = dict(re.findall(r"rank (\d): weights at the end ([0-9a-f]{16})", r.stderr))
+    assert sorted(ends) == ["0", "1"] and ends["0"] == ends["1"], ends
+    loaded = re.findall(r"rank (\d): weight set (\d) loaded", r.stderr)
+    assert ("0", "2") in loaded and ("1", "2") in loaded
+
+
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_cli_rolling_rounds_play_train_and_swap_weights_in_place(tmp_path, ranks):
     """``--rolling``: two overlapping rounds of 6 games through the CLI -- records of both rounds in id
