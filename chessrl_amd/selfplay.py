@@ -445,7 +445,11 @@ def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size
         def log_fn(summary):
             with open(os.path.join(model_dir, "train_log.jsonl"), "a") as f:
                 f.write(json.dumps(summary) + "\n")
-    history = trainer.fit_generator(gen, epochs=epochs, log=log_fn)
+    if group is not None:
+        from .train import fit_data_parallel
+        history = fit_data_parallel(trainer, gen, group=group, epochs=epochs, log=log_fn)
+    else:
+        history = trainer.fit_generator(gen, epochs=epochs, log=log_fn)
     return trainer.weights(), history
 
 
