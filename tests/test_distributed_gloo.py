@@ -364,3 +364,68 @@ def test_rolling_rounds_need_a_share_for_every_rank_and_count_empty_shares_as_co
     assert run.rounds_complete() == 3                                           # the empty share does not block
     run._round_done = {0: 2, 1: 1}
     assert run.rounds_complete() == 1
+
+
+def _dp_news_worker(rank, world, port, q):
+    """every rank has a trainer of its own (data-parallel mode): a weight set is loaded when EVERY rank has it"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import BackgroundTrainer, SelfPlayRunner
+    N, R = 2 * world, 2
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
+    run._round_done, run.finished = {}, []
+    mine = [g for g in range(N * R) if g % world == rank]
+    finish_at = {g: 5 * (k + 1) for k, g in enumerate(mine)}
+    state = {"move": 0}
+    run.active = lambda: np.array([state["move"] < max(finish_at.values()) + 60])
+
+    def play_move():
+        state["move"] += 1
+        time.sleep(0.01)
+        for g, m in finish_at.items():
+            if m == state["move"]:
+                run.finished.append(records.GameRecord(g, [1, 2, 3], 0, True))
+                run._round_done[g // N] = run._round_done.get(g // N, 0) + 1
+
+    run.play_move = play_move
+    ready_at = []
+
+    def train(w, recs):                                   # rank 1's trainer is three times slower
+        time.sleep(0.1 * (1 + 2 * rank))
+        ready_at.append(state["move"])
+        return dict(w, w=w["w"] + 1), [{"loss": 0.0}]
+
+    bg = BackgroundTrainer({"w": np.zeros(1)}, train_fn=train, group="own")      # (any non-None group: sets are kept)
+    loads = []
+    done = run.run_rolling(R, on_round=lambda r, recs: bg.submit(r, recs), sync_every=2, poll=bg.ready,
+                           on_news=lambda k: loads.append((k, state["move"], float(bg.take(k)["w"][0]))), news="min")
+    bg.drain()
+    run.sync_news(bg.ready, lambda k: loads.append((k, state["move"], float(bg.take(k)["w"][0]))), news="min")
+    bg.close()
+    q.put((rank, done, loads, ready_at))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_news_waits_for_the_slowest_trainer():
+    """news="min": a weight set is loaded, on every rank at the same sync index, only once EVERY rank's own
+    trainer has finished it, and it is that set -- not whatever a faster rank has finished since."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_dp_news_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=180) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (d0, l0, r0), (d1, l1, r1) = got[0], got[1]
+    assert d0 == d1 == 2
+    assert [(k, m) for k, m, _ in l0] == [(k, m) for k, m, _ in l1]             # same set at the same move
+    assert all(w == float(k) for k, _, w in l0 + l1) and l0[-1][0] == 2          # set k holds k training rounds
+    for (k, m, _) in l1:
+        assert m >= r1[k - 1]                                                     # not before the slow rank had it
