@@ -312,9 +312,10 @@ def test_ranks_keep_playing_while_rank_0_trains_in_the_background(world):
         assert [(k, m) for k, m, _ in loaded_at] == [(k, m) for k, m, _ in got[0][2]]
     # rank 0 itself played on while its trainer thread worked ...
     assert all(d > 0 for d in got[0][3][:2]), got[0][3]
-    # ... and rank 1 was never held: between two weight loads it ran simulations
+    # ... and rank 1 was never held: it was still simulating after the first weight set had arrived (the last
+    # sets may arrive together at the final drain, after the last move)
     loads1 = got[1][2]
-    assert len(loads1) >= 2 and all(b[2] > a[2] for a, b in zip(loads1, loads1[1:])), loads1
+    assert len(loads1) >= 2 and loads1[0][2] < got[1][4], (loads1, got[1][4])
 
 
 def test_background_trainer_trains_in_order_and_surfaces_its_errors():
