@@ -26,6 +26,35 @@ def test_library_exports_every_symbol_declared_in_the_header():
         assert hasattr(L, name), name
 
 
+def test_library_identity_and_refusal_of_a_stale_library(monkeypatch):
+    """The library carries the sha256 of the sources it was built from and an ABI version; a library built
+    from other sources that cannot be rebuilt is refused, and so is one of another ABI version (a ctypes
+    call through a stale signature would hand the GPU garbage pointers)."""
+    from chessrl_amd import _lib
+    L = _lib.lib()
+    text = open(os.path.join(ROOT, "include", "chessrl_hip.h")).read()
+    assert L.crl_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define CRL_ABI_VERSION (\d+)", text).group(1))
+    assert L.crl_source_hash().decode() == _lib.source_hash() == _lib.embedded_hash() and not _lib.is_stale()
+    # the sources change and hipcc is not there: no silent load of the old library
+    monkeypatch.setattr(_lib, "source_hash", lambda: "0" * 64)
+    assert _lib.is_stale()
+    monkeypatch.setattr(_lib, "_lib", None)
+
+    def no_compiler(*a, **k):
+        raise OSError("hipcc: not found")
+    monkeypatch.setattr(_lib, "build", no_compiler)
+    with pytest.raises(_lib.HipLibraryError, match="older than csrc"):
+        _lib.lib()
+    # another ABI version than the binding's
+    monkeypatch.undo()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.HipLibraryError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib() is not None
+
+
 @pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure path")
 def test_product_path_fails_loudly_without_gpu():
     from chessrl_amd import _lib
