@@ -233,6 +233,30 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
     assert not (np.array_equal(a["replies"], c["replies"]) and np.array_equal(a["visits"], c["visits"]))
 
 
+def test_hybrid_mode_plays_the_complete_games_of_the_split_precision_mode():
+    """Whole self-play games on a sharp net (refill, compaction of the thinning batch, Dirichlet noise, several
+    steps per hipGraph launch): the records played in ``hybrid`` are, move for move, the records played in pure
+    ``f16x3`` -- ~60 000 S1 evaluations, every reply choice the same."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    _, planes = _positions()
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+    out = {}
+    for mode in ("f16x3", "hybrid"):
+        model = ChessModel(weights=sharp, precision=mode)
+        model.HYBRID_MIN_BOARDS = 0
+        run = SelfPlayRunner(model, n_parallel=32, sims=8, seed=13, noise=True, total_games=48, max_plies=1024)
+        out[mode] = {r.game_id: r for r in run.run()}
+        if mode == "hybrid":
+            assert model.fallback_boards() > 0
+        run.close()
+    a, b = out["f16x3"], out["hybrid"]
+    assert sorted(a) == sorted(b) == list(range(48))
+    for k in a:
+        assert a[k] == b[k], k
+    assert len({len(r.moves) for r in a.values()}) > 10
+
+
 @pytest.mark.parametrize("disturbance", ["disturb", "stream"])
 def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu(disturbance):
     """Launch-to-launch identity of every trunk kernel family (64 / 128 / 256 filters, both
