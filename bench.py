@@ -92,6 +92,10 @@ def parse():
                    help="evaluate a weight file (.npz / Keras .h5; --blocks / --filters are taken from it) instead of a "
                         "random-init net: NOT the metric's configuration (BASELINE quotes random-init nets) -- for "
                         "measuring what the product runs once a net is trained; the line says so in config.workload")
+    p.add_argument("--dist-timeout-min", type=float, default=30.0,
+                   help="process-group timeout (N > 1): rank 0's post-window work -- parity gate against the fp32 "
+                        "oracle, phase profile, the other precision modes' legs -- runs while the other ranks wait in "
+                        "a collective; explicit so that no configuration depends on the backend's default watchdog")
     p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
                    help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
@@ -193,15 +197,17 @@ def init_ranks(a):
     # group, so the RCCL branch below, the reductions and the record gather execute on hardware
     if world == 1 and os.environ.get("CRL_BENCH_FORCE_GROUP") != "1":
         return rank, world, local, None
+    import datetime
     import torch.distributed as dist
     backend = os.environ.get("CRL_BENCH_BACKEND", "nccl")
+    timeout = datetime.timedelta(minutes=a.dist_timeout_min)
     with stdout_to_stderr():
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
             dev = torch.device("cuda", local)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
             dev = torch.device("cpu")
         t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
@@ -240,6 +246,10 @@ def profile_phases(run, n):
     for _ in range(max(0, run.sims // 2 - n)):
         eng.step()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
+    model = eng.evaluator
+    hooked = hasattr(model, "trunk_events")
+    if hooked:
+        model.trunk_events = []                 # every trunk launch of these steps bracketed by HIP events
     for i in range(n):
         ev[i][0].record()
         eng.phase_select_expand()
@@ -252,8 +262,20 @@ def profile_phases(run, n):
         ev[i][4].record()
     torch.cuda.synchronize()
     names = ["select_expand", "tower_s1", "reply", "tower_s2"]
-    return {nm: sum(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(n)) / n
-            for k, nm in enumerate(names)}
+    out = {nm: sum(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(n)) / n
+           for k, nm in enumerate(names)}
+    if hooked:
+        # the trunk kernel's own time INSIDE real steps (between the search kernels and the heads, at the clock
+        # the step holds), per arithmetic: {kind: (mean ms per launch, launches per step)}
+        kinds = {}
+        for kind, e0, e1 in model.trunk_events:
+            kinds.setdefault(kind, []).append(e0.elapsed_time(e1))
+        model.trunk_events = None
+        out["trunk_in_step"] = {k: {"launch_ms": sum(v) / len(v), "launches_per_step": len(v) / n} for k, v in kinds.items()}
+        trunk_ms = sum(sum(v) for v in kinds.values()) / n
+        out["heads_and_margin_ms"] = out["tower_s1"] + out["tower_s2"] - trunk_ms
+        out["trunk_ms_per_step"] = trunk_ms
+    return out
 
 
 def pmc_traffic(kernel, shape):
@@ -362,6 +384,18 @@ def time_record_gather(run, dist, max_plies):
             "what": "all_gather of counts + padded int32 record blocks incl. H2D/D2H staging, best of 3"}
 
 
+def group_timeout_s(dist):
+    """The timeout the process group really carries (read back from its backend options), in seconds."""
+    if dist is None:
+        return None
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        dev = torch.device("cuda") if dist.get_backend() == "nccl" else torch.device("cpu")
+        return pg._get_backend(dev).options._timeout.total_seconds()
+    except Exception:                                        # private API: the line then says "unknown"
+        return "unknown"
+
+
 def agree_max(dist, x, rdev):
     """max over ranks of a small integer (identity without a process group)."""
     if dist is None:
@@ -408,6 +442,7 @@ def dry_run(a, rank, world, dist):
         print(json.dumps({"metric": "MCTS simulations/sec at 800 sims/move", "value": None,
                           "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "mode_agreed": ["f16", "hybrid", "f16x3"][mode],
+                          "process_group_timeout_s": group_timeout_s(dist),
                           "per_rank": {"ms_per_step": spread([p[0] for p in per]),
                                        "trunk_launch_ms": spread([p[1] for p in per])},
                           "record_gather": {"records": int(rows.shape[0]), "backend": st.get("backend")}}),
@@ -536,6 +571,35 @@ def tower_error_vs_fp32(model, sets, precision):
     return out
 
 
+def issued_flops(F, B, G):
+    """MFMA FLOPs the split-precision trunk ISSUES per launch: three products per residual-conv MAC (hi.Whi,
+    lo.Whi, hi.Wlo), two for the stem (its 0/1 planes have no lo part); the 1x1 head convs run on the VALU."""
+    return 2.0 * (2 * 73152 * F + 3 * 1152 * F * F * B) * G
+
+
+def compliant_roofline(model, eng, ph, F, B, G, peak, shape):
+    """``roofline_compliant``: the kernel every evaluation under the 1e-3 bar runs when a net needs the compliant
+    mode (hybrid / f16x3: S2's priors and value) -- the split-precision trunk -- timed inside eager steps of that
+    mode on the same games and weights: algorithmic fraction (the three MFMAs of a product count once), issued
+    fraction, PMC traffic of that kernel at this shape."""
+    kern = trunk_kernel_name(F, G, int(eng.bitplanes) | 2)
+    ins = ph.get("trunk_in_step", {}).get("f16x3")
+    if ins is None:
+        return None
+    ms = ins["launch_ms"]
+    alg = 2.0 * (73152 * F + 1152 * F * F * B + 192 * F) * G
+    traffic, src = pmc_traffic(kern, shape)
+    plane_in = 1024 if eng.bitplanes else 64 * 128 * 2
+    return {"bound": "mfma", "kernel": "crl_tower::%s (split precision: hi/lo fp16 operands, three MFMAs per product)" % kern,
+            "launch_ms": ms, "launch_ms_source": "HIP events around the launch inside eager steps mid-move",
+            "flops_per_launch": alg, "achieved": alg / ms / 1e9, "peak": peak, "unit": "TFLOP/s",
+            "frac": alg / ms / 1e9 / peak,
+            "issued_flops_per_launch": issued_flops(F, B, G), "issued_frac": issued_flops(F, B, G) / ms / 1e9 / peak,
+            "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes": G * plane_in + 2 * (9 * 128 * F + 2 * B * 9 * F * F) * 2 + G * 192 * 4,
+            "trunk_in_step": ph["trunk_in_step"], "phase_ms": {k: ph[k] for k in ("select_expand", "tower_s1", "reply", "tower_s2")}}
+
+
 def tracked_whole_run():
     """Whole-game figures of the LAST tracked rolling-rounds run (tools/rolling_probe.py; not measured by
     this bench run): moves per game for the games/hour estimate and the measured games/hour, read from
@@ -658,6 +722,17 @@ def main():
         tower_ms = event_time_ms(eng.phase_tower_s2, 20)     # trunk + both heads, as the step runs them
         tower_flops = 2.0 * model.macs_per_eval() * G
         peak = MFMA_PEAK_TFLOPS[a.dtype]
+        ms_step = max_dt / a.steps * 1e3
+        boundary = time_move_boundary(run)               # rank 0 only; the other ranks wait at the last barrier
+        ph = profile_phases(run, 16)                     # eager steps mid-move: every phase and every trunk launch
+        main_kind = model._trunk_mode() if model.fused else None     # the arithmetic of the roofline's kernel
+        k_ms_b2b, in_step = k_ms, False
+        if model.fused and main_kind in ph.get("trunk_in_step", {}):
+            in_step = True
+            # the kernel's time INSIDE the steps (HIP events around the launch, on the launch stream): 50 launches
+            # back to back after the run hold a lower clock than a launch between search kernels and heads does --
+            # round 4's line carried a kernel time that did not fit twice into its own step
+            k_ms = ph["trunk_in_step"][main_kind]["launch_ms"]
         if model.fused:
             # the hand-written fused trunk: ONE launch per tower forward.  Algorithmic FLOPs per
             # launch = 2 x (stem 73152 F + blocks 1152 F^2 B + head convs 192 F) MACs per board
@@ -684,9 +759,23 @@ def main():
                 "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
                 "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": alg_bytes,
-                "launch_ms": k_ms, "flops_per_launch": k_flops,
+                "launch_ms": k_ms, "launch_ms_source": "HIP events around the launch inside 16 eager steps mid-move "
+                                                       "(profile_phases)" if in_step else
+                                                       "HIP events around 50 back-to-back launches",
+                "launch_ms_back_to_back": k_ms_b2b, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}
+        if model.fused and "trunk_ms_per_step" in ph:
+            # self-consistency: the step's kernels as timed inside eager steps must fit the timed step
+            parts = {"trunk_launches": ph["trunk_ms_per_step"], "heads": ph["heads_and_margin_ms"],
+                     "select_expand": ph["select_expand"], "reply": ph["reply"]}
+            total = sum(parts.values())
+            roof["step_fit"] = dict(parts, sum_ms=total, ms_per_step=ms_step, ratio=total / ms_step,
+                                    fits=bool(total <= 1.02 * ms_step),
+                                    trunk_in_step=ph["trunk_in_step"],
+                                    note="eager phases (HIP events) against the hipGraph-replayed timed step")
+            if main_kind == "f16x3":
+                roof["issued_frac"] = issued_flops(F, B, G) / k_ms / 1e9 / peak
         # ---- hand-written HIP search kernels (HBM-bound): select+expand and reply -----------
         # algorithmic bytes per simulation, SURVEY.md section 8d with the measured d and b;
         # with the fused trunk the encoders hand over 1-KiB plane bitboards (expanded on chip); any
@@ -700,8 +789,6 @@ def main():
         policy_bytes = (2 * branch * (2 + 4 + 4) if eng.legal_priors          # label u16 + prior f32 written + read
                         else 2 * (2 * 1968 * 4 + branch * 4))                  # full fp32 vectors written + read, gathered
         tree_bytes = (2400.0 - 2 * branch * 2) + 24.0 * depth * branch + policy_bytes + 2 * plane_bytes
-        boundary = time_move_boundary(run)               # rank 0 only; the other ranks wait at the last barrier
-        ph = profile_phases(run, 16)
         tree_ms = ph["select_expand"] + ph["reply"]
         t_traffic, t_src = pmc_traffic("k_select_expand + k_reply",
                                        "%d games, %s planes, %s" % (G, "bit" if eng.bitplanes else "fp16",
@@ -716,7 +803,6 @@ def main():
                                                          else "2 x (2 x 7872 B policy vectors + 4 B x branch)", int(plane_bytes)),
                 "mean_depth": depth, "mean_branch": branch}
         inside = (moves1 - moves0) // max(1, G)
-        ms_step = max_dt / a.steps * 1e3
         if boundary is not None:
             # whole moves at this step rate with the measured boundary: what a run of many moves sustains
             incl = G * a.sims / ((a.sims * ms_step + boundary["ms"]) * 1e-3) if inside == 0 else total_sims / max_dt
@@ -728,9 +814,12 @@ def main():
         # ---- both precision modes on the same games and weights: the timed one(s) over the K-step window,
         # the other one over a short window mid-move -----------------------------------------------------
         modes = None
+        # the timed mode already is the compliant one -> its own in-step profile; else filled in by the hybrid leg
+        compliant = (compliant_roofline(model, eng, ph, F, B, G, peak, shape)
+                     if model.fused and main_kind == "f16x3" else None)
         if model.fused:
             modes = {k: dict(v, window="the K timed steps") for k, v in timed.items()}
-            modes[model.precision].update(trunk_kernel=kern, trunk_launch_ms=k_ms)
+            modes[model.precision].update(trunk_kernel=kern, trunk_launch_ms=k_ms, trunk_launch_ms_back_to_back=k_ms_b2b)
             probe_dist = model.probe_error()
             keep = model.precision
             for other in ("f16", "hybrid", "f16x3"):
@@ -764,6 +853,7 @@ def main():
                 if other == "hybrid":
                     modes[other]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, nsim)
                     modes[other]["reply_margin"] = model.reply_margin
+                    compliant = compliant_roofline(model, eng, profile_phases(run, 8), F, B, G, peak, shape)
             if model.precision != keep:
                 model.set_precision(keep)
             modes["f16_vs_f16x3_on_probe"] = probe_dist
@@ -794,6 +884,7 @@ def main():
                                                      "ChessModel(precision='auto'): f16 kept only if within %g of f16x3 on "
                                                      "%d probe positions, else %s" % (model.PROBE_TOL, model.PROBE_POSITIONS,
                                                                                      model.AUTO_STRICT))),
+                       "tower_precision_guard": getattr(model, "guard", None),
                        "trunk_kernel": kern if model.fused else None,
                        "numpy_promotion": eng.numpy_promotion,
                        "parallelism": "games sharded, no collective on the hot path"},
@@ -811,7 +902,7 @@ def main():
                                                    if same_cfg else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),
             "gflop_per_sim": 2 * 2 * model.macs_per_eval() / 1e9,
-            "roofline": roof, "roofline_tree": tree, "precision_modes": modes,
+            "roofline": roof, "roofline_tree": tree, "roofline_compliant": compliant, "precision_modes": modes,
             "tower_error_vs_fp32": parity,
         }
         if gather is not None:

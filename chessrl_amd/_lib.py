@@ -42,6 +42,7 @@ FLAG_NUMPY_LEGACY = 1
 POLICY_FULL, POLICY_LEGAL, POLICY_LEGAL_RAW = 0, 1, 2
 TRUNK_BITPLANES = 1
 TRUNK_SPLIT = 2
+LIST_HEADER = 4          # include/chessrl_hip.h: CRL_LIST_HEADER (int32 words in front of a board list)
 
 # every symbol include/chessrl_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -64,7 +65,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
+ABI_VERSION = 7          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
 _HASH_MARK = b"CRL_SRC_HASH="
 
 
@@ -203,7 +204,7 @@ def lib():
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_set_plane_format.argtypes = [vp, i32]
-    L.crl_reply_margin.argtypes = [vp, vp, vp, i32, ctypes.c_float, i32, vp]
+    L.crl_reply_margin.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     L.crl_trunk_forward_indexed.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]

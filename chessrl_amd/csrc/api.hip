@@ -712,16 +712,16 @@ int crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bit
 }
 
 int crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
-                     float log_margin, int rows_are_logits, int32_t *dev_list)
+                     const float *dev_log_margin_f32, int rows_are_logits, int32_t *dev_list)
 {
-    if (!dev_priors_f32 || !dev_counts || n_boards < 1 || !dev_list || !(log_margin >= 0.f))
+    if (!dev_priors_f32 || !dev_counts || n_boards < 1 || !dev_list || !dev_log_margin_f32)
         return fail(nullptr, CRL_ERR_ARG, "crl_reply_margin: bad argument");
     hipStream_t st = (hipStream_t)hip_stream;
     hipLaunchKernelGGL(crl_heads::k_zero_word, dim3(1), dim3(64), 0, st, (int *)dev_list);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     hipLaunchKernelGGL(crl_heads::k_reply_margin, dim3((unsigned)((n_boards + 3) / 4)), dim3(256), 0, st,
-                       (const float *)dev_priors_f32, (const int *)dev_counts, n_boards, log_margin,
+                       (const float *)dev_priors_f32, (const int *)dev_counts, n_boards, dev_log_margin_f32,
                        rows_are_logits ? 1 : 0, (int *)dev_list);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));

@@ -409,9 +409,12 @@ __global__ __launch_bounds__(256) void k_policy_normalise(float *__restrict__ po
 // (agentdistributed.py:57-58).  In the hybrid mode S1 runs the single-MFMA trunk first; this kernel lists the
 // boards whose choice is not safe against that arithmetic's error: the log-margin of the two best legal
 // moves, log p1 - log p2 (= the difference of their logits: a rounding error of the trunk moves a logit,
-// i.e. a probability by a FACTOR), is below `log_margin`.  One wave per board.  list: int32 [2 + n_boards]:
-// [0] boards listed by this launch (zeroed by the caller), [1] running total of listed boards (statistics),
-// [2 + k] the boards, in no particular order (the consumers do not depend on it).
+// i.e. a probability by a FACTOR), is below *log_margin -- read from DEVICE memory: the margin belongs to the
+// weight set, weights are rewritten in place under captured hipGraphs, and a by-value kernel argument would
+// stay what it was at capture.  One wave per board.  list: int32 [LIST_HEADER + n_boards]:
+// [0] boards listed by this launch (zeroed by the caller), [1] unused, [2..3] one 64-bit running total of listed
+// boards (statistics; an int32 wrapped after ~13 k C3 moves), [LIST_HEADER + k] the boards, in no particular
+// order (the consumers do not depend on it).
 // (the list's counter is zeroed by a kernel, not by hipMemsetAsync: a 4-byte memset node captured into a
 // hipGraph did not run at replay on this stack -- the counter kept growing, the list overflowed)
 __global__ __launch_bounds__(64) void k_zero_word(int *__restrict__ word)
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64) void k_zero_word(int *__restrict__ word)
 }
 
 __global__ __launch_bounds__(256) void k_reply_margin(const float *__restrict__ priors, const int *__restrict__ counts,
-                                                      int n_boards, float log_margin, int rows_are_logits,
+                                                      int n_boards, const float *__restrict__ log_margin_p, int rows_are_logits,
                                                       int *__restrict__ list)
 {
     const int lane = threadIdx.x & 63, board = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -444,10 +447,10 @@ __global__ __launch_bounds__(256) void k_reply_margin(const float *__restrict__ 
     float margin;
     if (rows_are_logits) margin = m1 - m2;
     else margin = m2 > 0.f ? __logf(m1 / m2) : (m1 > 0.f ? __builtin_inff() : 0.f);
-    if (lane == 0 && !(margin >= log_margin)) {           // (NaN counts as unsafe)
+    if (lane == 0 && !(margin >= *log_margin_p)) {        // (NaN counts as unsafe)
         const int k = atomicAdd(list, 1);
-        list[2 + k] = board;
-        atomicAdd(list + 1, 1);
+        list[crl_tower::LIST_HEADER + k] = board;
+        atomicAdd(reinterpret_cast<unsigned long long *>(list + 2), 1ull);
     }
 }
 

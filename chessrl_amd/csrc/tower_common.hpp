@@ -51,6 +51,7 @@ constexpr int ROW_BYTES = CH * 2;             // one position of the fp16 input 
 constexpr int BOARD_BYTES = 64 * ROW_BYTES;   // 16 KiB
 constexpr int MAX_CONVS = 41;                 // stem + 2 * 20 blocks
 constexpr int PIPE_RING = 4;                  // weight tiles in the plain LDS ring
+constexpr int LIST_HEADER = 4;                // int32 words in front of a board list (CRL_LIST_HEADER, include/chessrl_hip.h)
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 

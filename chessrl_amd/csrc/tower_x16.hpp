@@ -193,9 +193,9 @@ template <int N> __device__ __forceinline__ void wait_lgkm()
 // group the six sub-steps run back to back with their fragments fetched TWO sub-steps ahead into
 // three register buffers, across tap boundaries (not across layers: those activations do not exist yet).
 // IDX = 1 (the fall-back launch of the hybrid precision mode, crl_trunk_forward_indexed): the launch covers a
-// LIST of boards.  `out` is then not an output but the list, int32 [2 + n]: [0] = number of listed boards
+// LIST of boards.  `out` is then not an output but the list, int32 [LIST_HEADER + n]: [0] = number of listed boards
 // (a workgroup beyond it exits at once: the grid is sized for the worst case, the list is written on the
-// device), [1] unused here, [2 + k] = the board (row of `planes` and of `head_out`) the k-th resident board
+// device), [1 .. 3] unused here (statistics, csrc/heads.hpp), [LIST_HEADER + k] = the board (row of `planes` and of `head_out`) the k-th resident board
 // is.  A list that does not fill the last workgroup is padded with its last entry (the same board computed
 // twice writes the same values twice).  Nothing else changes: the production kernels (IDX = 0) compile as
 // they did.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
 #pragma unroll
         for (int b = 0; b < G::NB; b++) {
             const int k = (int)wg_board0 + b < listed ? (int)wg_board0 + b : listed - 1;
-            rows[b] = __builtin_amdgcn_readfirstlane(list[2 + k]);
+            rows[b] = __builtin_amdgcn_readfirstlane(list[LIST_HEADER + k]);
         }
     }
 

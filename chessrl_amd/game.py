@@ -47,6 +47,24 @@ def uci_to_move(u):
     return (r0 * 8 + f0) | ((r1 * 8 + f1) << 6) | (p << 12)
 
 
+def clean_castling_rights(cas, kings, rooks, white):
+    """python-chess ``Board.clean_castling_rights()`` (standard chess), which ``chess.Board(fen)`` applies wherever
+    it uses the rights -- move generation, ``push`` and the transposition key of the repetition rules
+    (game.py:17-21,92-109): a right survives only with its king on e1 / e8 and a rook of that colour on its
+    corner.  The device hashes the bits as they stand (csrc/board.hpp: key_bits), so a FEN claiming more than the
+    position holds is cleaned HERE: otherwise a king's first move would change the key where python-chess sees
+    the same position again, and fivefold counts would differ.  cas: K=1, Q=2, k=4, q=8."""
+    black = ~white
+    wk, bk = (kings & white) >> 4 & 1, (kings & black) >> 60 & 1
+    wr, br = rooks & white, rooks & black
+    keep = 0
+    keep |= 1 if (wk and (wr >> 7) & 1) else 0
+    keep |= 2 if (wk and wr & 1) else 0
+    keep |= 4 if (bk and (br >> 63) & 1) else 0
+    keep |= 8 if (bk and (br >> 56) & 1) else 0
+    return cas & keep
+
+
 def board_row_from_fen(fen):
     """FEN (piece placement, optionally the full record) -> np.uint64[8] crl_board row."""
     parts = fen.split()
@@ -68,6 +86,7 @@ def board_row_from_fen(fen):
     cas = 0
     if len(parts) > 2:
         cas = sum(bit for ch, bit in (("K", 1), ("Q", 2), ("k", 4), ("q", 8)) if ch in parts[2])
+        cas = clean_castling_rights(cas, bb[5], bb[3], white)
     ep = NO_EP
     if len(parts) > 3 and parts[3] != "-":
         ep = _FILES.index(parts[3][0]) + 8 * (int(parts[3][1]) - 1)

@@ -244,6 +244,8 @@ class ChessModel(object):
                              # are two workgroup rounds, and a batch this small is one or two rounds of the split
                              # kernel anyway (C2's 512 boards: hybrid 0.351 ms per step against 0.288 in f16x3)
     AUTO_STRICT = "hybrid"   # what "auto" runs when f16 is not within PROBE_TOL ("f16x3" = no S1 shortcut)
+    GUARD_TOL = 9e-4         # run-time guard of an auto-kept "f16": |f16 - f16x3| on the run's OWN tree leaves beyond
+                             # which the model leaves f16 for AUTO_STRICT (f16x3 is within 1e-4 of fp32: 1e-3 in all)
 
     def __init__(self, compile_model=False, weights=None, blocks=10, filters=256, device="cuda:0",
                  dtype=torch.float16, seed=0, fused=True, precision="auto"):
@@ -255,8 +257,13 @@ class ChessModel(object):
         self.precision = None                    # resolved per weight set ("f16" / "f16x3"; the dtype otherwise)
         self.precision_probe = None              # what "auto" measured
         self.reply_margin = None                 # hybrid: log-margin below which an S1 board is evaluated again
+        self._reply_margin_dev = None            # ... as the kernel reads it: ONE float in device memory, rewritten in
+                                                 # place with every weight set (a by-value argument would stay what it
+                                                 # was when a hipGraph captured the launch)
         self._fallback = {}                      # hybrid: batch size -> the device list of boards to evaluate again
         self.graph_epoch = 0                     # bumped when the kernel a captured graph holds changes
+        self.trunk_events = None                 # bench.py: a list -> every trunk launch is bracketed by HIP events
+        self.guard = {"checks": 0, "positions": 0, "worst": 0.0, "fired": None}   # guard_check's record
         self._scratch = {}                       # batch size -> slice statistics of the small-batch heads
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -444,6 +451,7 @@ class ChessModel(object):
                                        "precision=%r): use set_precision() or precision='auto'"
                                        % ("f16x3" if split else "f16", self.precision_requested))
         flags = (_lib.TRUNK_BITPLANES if bits else 0) | (_lib.TRUNK_SPLIT if split else 0)
+        ev = self._trunk_event("f16x3" if split else "f16")
         rc = _lib.lib().crl_trunk_forward_x(
             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters, flags,
             ctypes.c_void_p(planes.data_ptr()), ctypes.c_void_p(image.data_ptr()),
@@ -453,7 +461,20 @@ class ChessModel(object):
             ctypes.c_void_p(heads.data_ptr()))
         if rc != 0:
             raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
+        if ev is not None:
+            ev[2].record()
         return planes, heads, trunk
+
+    def _trunk_event(self, kind):
+        """Measurement hook (bench.py's in-step kernel time): with ``trunk_events`` a list, every trunk launch is
+        bracketed by two HIP events recorded on the launch stream -- (kind, start, end) is appended here, the
+        caller records ``end`` behind its launch.  None (the default) costs one attribute test."""
+        if self.trunk_events is None:
+            return None
+        ev = (kind, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[1].record()
+        self.trunk_events.append(ev)
+        return ev
 
     def _trunk_mode(self, precision=None):
         """The trunk arithmetic of a full evaluation in mode ``precision`` (default: the resolved mode):
@@ -510,11 +531,49 @@ class ChessModel(object):
             else:
                 self.precision = "f16" if max(dp, dv) <= self.PROBE_TOL else self.AUTO_STRICT
             self.reply_margin = self.HYBRID_K * dlog
+            self._publish_reply_margin()
             self.precision_probe = {"positions": int(planes.shape[0]), "dpolicy_max": dp, "dvalue_max": dv,
                                     "dlog_policy_max": dlog, "tolerance": self.PROBE_TOL, "chosen": self.precision,
                                     "reply_margin": self.reply_margin if self.precision == "hybrid" else None}
         if before is not None and before != self.precision:
             self.graph_epoch += 1
+
+    @torch.no_grad()
+    def guard_check(self, planes):
+        """Run-time guard of a mode that "auto" chose on a PROBE: the probe is 4096 positions of a fixed tiny net's
+        games, a run evaluates millions of its own (8e-4 on the probe leaves little margin for their
+        maximum).  While the model runs an auto-kept "f16", the self-play runner hands over, every few moves, the
+        tower inputs its search has just evaluated (the G tree leaves of the last simulation); they are evaluated
+        in both arithmetics and beyond GUARD_TOL the model leaves f16 for AUTO_STRICT -- from the next step on
+        (``graph_epoch``: engines capture again).  Returns max |f16 - f16x3| over policy and value, or None when
+        there is nothing to guard (a mode asked for by name, a strict mode, the PyTorch tower)."""
+        if not (self.fused and self.precision == "f16" and self.precision_requested == "auto"):
+            return None
+        pa, va = self._forward_fused(planes, precision="f16")
+        pb, vb = self._forward_fused(planes, precision="f16x3")
+        d = max(float((pa - pb).abs().max()), float((va - vb).abs().max()))
+        g = self.guard
+        g["checks"] += 1
+        g["positions"] += int(planes.shape[0])
+        g["worst"] = max(g["worst"], d)
+        if d > self.GUARD_TOL:
+            g["fired"] = {"after_checks": g["checks"], "after_positions": g["positions"], "distance": d,
+                          "tolerance": self.GUARD_TOL, "from": "f16", "to": self.AUTO_STRICT}
+            self.precision = self.AUTO_STRICT
+            self.graph_epoch += 1
+            if self.precision_probe is not None:
+                self.precision_probe = dict(self.precision_probe, chosen=self.precision, guard=g["fired"],
+                                            reply_margin=self.reply_margin)
+        return d
+
+    def _publish_reply_margin(self):
+        """Write ``reply_margin`` into the device float crl_reply_margin reads (allocated once, rewritten in
+        place: captured graphs hold its address and see the margin of the weights they run with)."""
+        src = torch.tensor([float(self.reply_margin)], dtype=torch.float32)
+        if self._reply_margin_dev is None:
+            self._reply_margin_dev = src.to(self.device)
+        else:
+            self._reply_margin_dev.copy_(src)
 
     def _forward_fused(self, planes, pol_out=None, val_out=None, precision=None):
         """Fused trunk + head convs in one HIP kernel, then the dense layers (model.py:44-48,56-61)
@@ -592,16 +651,20 @@ class ChessModel(object):
             heads(hp_full[:b])
             lst = self._fallback.get(bp)
             if lst is None:
-                lst = self._fallback[bp] = torch.zeros(2 + bp, dtype=torch.int32, device=self.device)
-            rc = L.crl_reply_margin(stream, vp(priors_out.data_ptr()), vp(counts_ptr), b, float(self.reply_margin),
-                                    0 if stats_out is None else 1, vp(lst.data_ptr()))
+                lst = self._fallback[bp] = torch.zeros(_lib.LIST_HEADER + bp, dtype=torch.int32, device=self.device)
+            rc = L.crl_reply_margin(stream, vp(priors_out.data_ptr()), vp(counts_ptr), b,
+                                    vp(self._reply_margin_dev.data_ptr()), 0 if stats_out is None else 1,
+                                    vp(lst.data_ptr()))
             if rc != 0:
                 raise _lib.HipLibraryError("crl_reply_margin failed (%d)" % rc)
+            ev = self._trunk_event("f16x3 indexed")
             rc = L.crl_trunk_forward_indexed(stream, self.filters, vp(planes_p.data_ptr()), vp(self._wtiles3.data_ptr()),
                                              vp(self._wbias.data_ptr()), bp, self.blocks, vp(self._head_w.data_ptr()),
                                              vp(self._head_b.data_ptr()), vp(hp_full.data_ptr()), vp(lst.data_ptr()))
             if rc != 0:
                 raise _lib.HipLibraryError("crl_trunk_forward_indexed failed (%d)" % rc)
+            if ev is not None:
+                ev[2].record()
             heads(hp_full[:b])
             return
         _, hp = self._run_fused(planes)
@@ -611,16 +674,17 @@ class ChessModel(object):
         """Allocate what an evaluation of ``n_boards`` keeps between calls (the hybrid mode's device list with its
         running counter) NOW: LockstepEngine calls this before it captures its hipGraph, so that no buffer
         is created -- and zero-filled at every replay -- inside the captured step."""
+        from . import _lib
         bp = (int(n_boards) + 3) // 4 * 4
         if self.fused and bp not in self._fallback:
-            self._fallback[bp] = torch.zeros(2 + bp, dtype=torch.int32, device=self.device)
+            self._fallback[bp] = torch.zeros(_lib.LIST_HEADER + bp, dtype=torch.int32, device=self.device)
         if self.fused:
             self._heads_scratch(int(n_boards))
 
     def fallback_boards(self):
         """hybrid: total number of S1 boards evaluated a second time since the model was built (sum over
-        the batch sizes it has served; a device-to-host read)."""
-        return int(sum(int(v[1].item()) for v in self._fallback.values()))
+        the batch sizes it has served; a device-to-host read of the lists' 64-bit counters)."""
+        return int(sum(int(v[2:4].view(torch.int64).item()) for v in self._fallback.values()))
 
     def raw_priors_supported(self, n_boards):
         """Whether a batch of ``n_boards`` is served by the sliced heads, i.e. may leave the softmax

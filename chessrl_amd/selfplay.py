@@ -102,6 +102,7 @@ class SelfPlayRunner(object):
         self.moves_played = 0
         self.sims_run = 0
         self.truncated_games = 0                 # records handed over at max_plies (result None)
+        self.boundaries = 0                      # move boundaries crossed
         self._sims_in_move = None
         self._noise_rows = None                  # this move's Dirichlet draws, made while the GPU searches
         self._noise_states = {}                  # ... and every drawn stream's state before its draw
@@ -239,7 +240,22 @@ class SelfPlayRunner(object):
             next_legal = None                               # slots were reset / moved: count again
         if self.noise:
             self._root_legal = next_legal if next_legal is not None else eng.ctx.legal_counts()
+        self.boundaries += 1
+        if self.GUARD_EVERY and self.boundaries % self.GUARD_EVERY == 0:
+            # an evaluator that chose its arithmetic on a probe (ChessModel precision="auto" -> "f16") is shown the
+            # tower inputs this search has just evaluated and may leave that mode (model.py: guard_check)
+            check = getattr(eng.evaluator, "guard_check", None)
+            if check is not None and eng.bitplanes:
+                before = getattr(eng.evaluator, "precision", None)
+                d = check(eng.planes_s2)
+                if d is not None and getattr(eng.evaluator, "precision", None) != before:
+                    log.warning("tower precision guard: |f16 - f16x3| = %.2e on this run's own tree leaves (tolerance "
+                                "%.1e): %s -> %s from the next move on", d, eng.evaluator.GUARD_TOL, before,
+                                eng.evaluator.precision)
         return live
+
+    GUARD_EVERY = 8          # move boundaries between two guard checks (one f16 + one f16x3 evaluation of the batch:
+                             # ~5 ms per 8 moves of ~1.9 s at C3)
 
     COMPACT_MIN = 64
 
@@ -407,14 +423,25 @@ class SelfPlayRunner(object):
         self.engine.close()
 
 
+def trainable_records(records):
+    """The records a training round learns from: at least one move and a RESULT.  A game the runner cut off at
+    ``max_plies`` has none (``Game.get_result()`` of a running game, game.py:92-109) -- whether it still carries
+    ``GameRecord.truncated`` (in process, over the wire) or was stored and reloaded (``get_history()`` /
+    gameplays.json keep only ``result: null``): ``DataGameSequence`` would refuse it as an unfinished game."""
+    keep = []
+    for r in records:
+        h = r.get_history()
+        if len(h["moves"]) > 0 and h.get("result") is not None and not getattr(r, "truncated", False):
+            keep.append(r)
+    return keep
+
+
 def train_model_job(model, records, model_path, model_dir, epochs=1, batch_size=1):
     """selfplay.py:98-108: train on the recorded games and save the weights.  ``records`` are
     ``GameRecord``s (or ``Game``s): anything with ``get_history()``."""
     from .dataset import DatasetGame
     from .netencoder import DataGameSequence
-    # (a record the runner cut off at max_plies has no result to learn a value from: game.py:92-109)
-    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0
-                              and not getattr(r, "truncated", False)])
+    data_train = DatasetGame(trainable_records(records))
     if len(data_train) == 0:
         return None
     gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
@@ -432,8 +459,7 @@ def train_weights(weights, records, device, model_dir=None, epochs=1, batch_size
     from .dataset import DatasetGame
     from .netencoder import DataGameSequence
     from .train import Trainer
-    data_train = DatasetGame([r for r in records if len(r.get_history()["moves"]) > 0
-                              and not getattr(r, "truncated", False)])
+    data_train = DatasetGame(trainable_records(records))
     if len(data_train) == 0 and group is None:
         return weights, None
     gen = DataGameSequence(data_train, batch_size=batch_size, random_flips=.1)   # agent.py:81-83
@@ -597,7 +623,9 @@ def main(argv=None):
                              "per game in the reference's order (selfplay.py:98-108; one GPU trains ~25 k positions/s, "
                              "eight produce ~35 k/s at C3: the weights lag); 'dp' = every rank trains on ITS games, "
                              "gradients averaged over RCCL, one Adam step per <ranks> games -- not the reference's "
-                             "arithmetic, but a trainer that scales with the GPUs")
+                             "arithmetic, but a trainer that scales with the GPUs.  EXPERIMENTAL: exercised on gloo ranks "
+                             "only; on the nccl backend two communicators are driven from two unordered threads of one "
+                             "process, which RCCL does not promise to survive")
     parser.add_argument("--trainer-share", type=float, default=0.2,
                         help="--rolling: fraction of rank 0's wall time its self-play leaves to the background trainer "
                              "WHILE a round is waiting to be trained (a pause after every move; the trainer's thousands "
@@ -623,6 +651,7 @@ def main(argv=None):
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO)
 
     import datetime
+    import sys
     import torch
     import torch.distributed as dist
     from .model import ChessModel
@@ -652,6 +681,10 @@ def main(argv=None):
     # (data-parallel: the trainer THREADS of all ranks talk over a process group of their own -- a communicator
     # serves one thread at a time, and the main threads keep using the default group)
     train_group = dist.new_group(backend=dist.get_backend(), timeout=datetime.timedelta(minutes=args.dist_timeout_min)) if dp else None
+    if dp and dist.get_backend() == "nccl" and rank == 0:
+        print("selfplay: --train-mode dp is EXPERIMENTAL on the nccl backend (two communicators driven from two "
+              "unordered threads per process; never run on RCCL ranks) -- 'rank0' is the reference's arithmetic",
+              file=sys.stderr, flush=True)
     background = (BackgroundTrainer(model.weights, "cuda:%d" % local, path if rank == 0 else None, args.model_dir if rank == 0 else None,
                                     group=train_group)
                   if (args.rolling and not args.no_train and (rank == 0 or dp)) else None)

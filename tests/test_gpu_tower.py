@@ -18,8 +18,8 @@ per product: fp32-grade).  Measured on MI355X (profiles/r03/tower_sharp_probe.js
 and 6e-3 .. 2.4e-2 off on the sharp ones; f16x3 is within 1e-4 on all.  ``precision="auto"`` (the
 product's default) must therefore pick a mode that meets 1e-3 on the real positions -- asserted here
 for what it picks, whatever that is -- and must pick f16x3 for the sharp nets; f16 must NOT meet the
-bar there (negative control: the comparison is able to fail), and on default-init nets f16 is
-asserted at the bound it was measured at (2e-3), the figure bench.py's mode carries.
+bar there (negative control: the comparison is able to fail).  Plain f16 has ONE bar: 1e-3, required of every
+net "auto" keeps in it -- on positions other than the probe's, for a grid of seeds -- and of no other.
 """
 import numpy as np
 import pytest
@@ -90,7 +90,72 @@ def test_tower_within_1e3_on_real_selfplay_positions(blocks, filters, weights):
         dp16, dv16 = _errors(p16, v16, epol, eval_)
         print("    f16 on the same weights: |dpolicy| max %.2e, |dvalue| max %.2e p99.9 %.2e, %d of %d positions beyond 1e-3"
               % (dp16.max(), dv16.max(), np.quantile(dv16, 0.999), int(((dp16 > 1e-3) | (dv16 > 1e-3)).sum()), N_POSITIONS))
-        assert dp16.max() <= 1e-3 and dv16.max() <= 2e-3 and np.quantile(dv16, 0.99) <= 1e-3
+        # ONE bar for one mode: plain f16 is only REQUIRED inside 1e-3 on nets for which "auto" keeps
+        # it -- that is the assertion above whenever model.precision == "f16", and
+        # test_every_net_auto_keeps_in_f16_is_inside_1e3_on_positions_other_than_the_probe for a grid of seeds;
+        # where "auto" left f16, f16 is merely reported (bounded drift: the comparison is sane)
+        assert max(dp16.max(), dv16.max()) < 0.1
+        if model.precision == "f16":
+            assert dp16.max() <= 1e-3 and dv16.max() <= 1e-3
+
+
+def test_every_net_auto_keeps_in_f16_is_inside_1e3_on_positions_other_than_the_probe():
+    """VERDICT r4 (#4): the inverse of the tolerance.  For the grid of profiles/r04/auto_decisions_c3_seeds.json --
+    eight random-init 10x128 nets as bench.py builds them (``--seed s``) plus two 6x64 ones -- every net that
+    ``auto`` KEEPS in f16 must be inside 1e-3 of the fp32 oracle on the 4096 self-play positions of THIS file
+    (other games, another net's play than the probe's).  If one fails, PROBE_TOL is too loose."""
+    from chessrl_amd.model import ChessModel, init_weights
+    x_bits, planes = _positions()
+    kept, left = [], []
+    for blocks, filters, seed in [(10, 128, s) for s in range(8)] + [(6, 64, 0), (6, 64, 2)]:
+        w = init_weights(blocks, filters, seed)
+        model = ChessModel(weights=w)
+        probe = max(model.precision_probe["dpolicy_max"], model.precision_probe["dvalue_max"])
+        if model.precision != "f16":
+            left.append((blocks, filters, seed, probe))
+            continue
+        epol, eval_ = tower_oracle.forward(w, planes)
+        pol, val = model(x_bits)
+        dp, dv = _errors(pol, val, epol, eval_)
+        kept.append((blocks, filters, seed, probe, float(dp.max()), float(dv.max())))
+        print("%dx%d seed %d: probe %.2e -> f16 kept; %d other positions vs fp32: |dpolicy| %.2e |dvalue| %.2e"
+              % (blocks, filters, seed, probe, N_POSITIONS, dp.max(), dv.max()))
+    print("auto left f16 for:", [(b, f, s, "%.2e" % p) for b, f, s, p in left])
+    assert kept, "the grid no longer holds a net auto keeps in f16: the test is vacuous"
+    for b, f, s, probe, dp, dv in kept:
+        assert probe <= ChessModel.PROBE_TOL and dp <= 1e-3 and dv <= 1e-3, (b, f, s, probe, dp, dv)
+
+
+def test_the_run_time_guard_takes_an_auto_kept_f16_off_a_net_that_misses_the_bar_on_the_runs_own_positions():
+    """the probe is 4096 positions of a fixed tiny net's games; a run evaluates millions of its own.
+    ``SelfPlayRunner`` shows the model the tower inputs its search has just evaluated every GUARD_EVERY move
+    boundaries (model.guard_check): a net that "auto" kept in f16 but that is beyond GUARD_TOL there leaves f16 for
+    hybrid in mid-run.  Forced here: a sharp net with the probe's tolerance opened so that auto keeps f16."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    _, planes = _positions()
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+
+    class Lenient(ChessModel):
+        PROBE_TOL = 1.0
+    model = Lenient(weights=sharp)                                   # auto, and the probe lets everything pass
+    assert model.precision == "f16" and model.guard["checks"] == 0
+    run = SelfPlayRunner(model, n_parallel=64, sims=8, seed=3, noise=True, max_plies=512)
+    run.GUARD_EVERY = 2
+    epoch = model.graph_epoch
+    for _ in range(2):
+        run.play_move()
+    assert model.guard["checks"] == 1 and model.guard["fired"] is not None and model.guard["worst"] > model.GUARD_TOL
+    assert model.precision == "hybrid" and model.graph_epoch == epoch + 1
+    run.play_move()                                                  # goes on in the compliant mode (graphs re-captured)
+    assert model.guard["checks"] == 1                                # nothing left to guard
+    run.close()
+    # a mode asked for by name is not second-guessed; a soft net passes its checks
+    named = ChessModel(weights=sharp, precision="f16")
+    assert named.guard_check(_positions()[0][:64]) is None and named.precision == "f16"
+    soft = ChessModel(blocks=2, filters=64, seed=1)
+    d = soft.guard_check(_positions()[0][:256])
+    assert soft.precision == "f16" and d is not None and d < soft.GUARD_TOL and soft.guard["positions"] == 256
 
 
 def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
@@ -151,13 +216,15 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
                     want.add(b)
                 elif margin < thr * (1 + 1e-4):
                     want.add(-1)                                      # too close to the threshold to assert
-        lst = torch.full((2 + n,), -5, dtype=torch.int32, device="cuda")
-        lst[1] = 100
+        H = _lib.LIST_HEADER
+        lst = torch.full((H + n,), -5, dtype=torch.int32, device="cuda")
+        lst[2:4] = torch.tensor([2 ** 31 - 3, 0], dtype=torch.int32)  # the 64-bit running total, about to pass 2^31
+        thr_dev = torch.tensor([thr], dtype=torch.float32, device="cuda")        # the margin is read from device memory
         assert L.crl_reply_margin(st, vp(torch.from_numpy(rows).cuda().data_ptr()), vp(torch.from_numpy(counts).cuda().data_ptr()),
-                                  n, thr, int(logits), vp(lst.data_ptr())) == 0
+                                  n, vp(thr_dev.data_ptr()), int(logits), vp(lst.data_ptr())) == 0
         got = lst.cpu().numpy()
-        listed = set(got[2:2 + got[0]].tolist())
-        assert got[1] == 100 + got[0] and len(listed) == got[0]
+        listed = set(got[H:H + got[0]].tolist())
+        assert got[1] == -5 and int(got[2:4].view(np.int64)[0]) == 2 ** 31 - 3 + int(got[0]) and len(listed) == got[0]
         assert listed - want <= set() or -1 in want
         assert (want - {-1}) <= listed and 5 in listed and not ({0, 1} & listed)
     for blocks, filters, n in ((1, 64, 64), (1, 64, 1024), (1, 128, 64), (1, 256, 64)):
@@ -168,9 +235,9 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
         _, h48 = m._run_fused(planes, precision="f16x3")
         assert not torch.equal(h16, h48)
         for pick in ([0], [5, 17, 40], list(range(1, n, 3)), []):
-            lst = torch.zeros(2 + n, dtype=torch.int32, device="cuda")
+            lst = torch.zeros(_lib.LIST_HEADER + n, dtype=torch.int32, device="cuda")
             lst[0] = len(pick)
-            lst[2:2 + len(pick)] = torch.tensor(pick, dtype=torch.int32)[torch.randperm(len(pick))] if pick else 0
+            lst[_lib.LIST_HEADER:_lib.LIST_HEADER + len(pick)] = torch.tensor(pick, dtype=torch.int32)[torch.randperm(len(pick))] if pick else 0
             hp = h16.clone()
             assert L.crl_trunk_forward_indexed(st, filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
                                                vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()),
@@ -179,6 +246,72 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
             mask = torch.zeros(n, dtype=torch.bool, device="cuda")
             mask[pick] = True
             assert torch.equal(hp[mask], h48[mask]) and torch.equal(hp[~mask], h16[~mask]), (filters, n, len(pick))
+
+
+def _random_playouts(eng, target, picks):
+    """the same random playouts for every engine: game g plays target[g] plies chosen by picks[ply][g]"""
+    G = len(target)
+    for ply in range(int(target.max())):
+        moves, counts = eng.ctx.legal_moves()
+        pick = (picks[ply] * np.maximum(counts, 1)).astype(np.int64)
+        mv = np.where((target > ply) & (counts > 0), moves[np.arange(G), pick], 0xFFFF).astype(np.uint16)
+        eng.ctx.push_moves(mv)
+
+
+def test_a_weight_reload_under_a_captured_hybrid_graph_searches_with_the_new_margin():
+    """the reply margin belongs to the weight set.  hybrid -> hybrid reloads keep the captured
+    hipGraph (the weights are rewritten in place), so the margin must reach the kernel through device memory: a
+    by-value argument would stay the margin of the weights the graph was captured with.  A graph captured on a
+    soft net (margin ~1e-3) is replayed after ``load_dict`` of a sharp net (margin 30-100x larger): the trees, the
+    replies and the number of boards evaluated twice are those of a fresh model of the sharp net driven WITHOUT
+    graphs; with the stale margin the fall-back list would be a fraction of it."""
+    from chessrl_amd.engine import LockstepEngine
+    from chessrl_amd.model import ChessModel
+    _, planes = _positions()
+    soft = tower_oracle.init_weights(6, 64, seed=4)
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+    G, sims = 512, 32
+    rng = np.random.RandomState(12)
+    target = rng.randint(0, 100, size=G)
+    picks = rng.random_sample((int(target.max()), G))
+
+    model = ChessModel(weights=soft, precision="hybrid")
+    model.HYBRID_MIN_BOARDS = 0
+    margin_soft = model.reply_margin
+    eng = LockstepEngine(model, G, sims)
+    eng.reset()
+    _random_playouts(eng, target, picks)
+    eng.search(sims)                                                 # captures the step graphs on the soft net
+    graphs, epoch = dict(eng._graphs), model.graph_epoch
+    assert graphs
+    fb_soft = model.fallback_boards()
+    model.load_dict(sharp)                                           # in place; hybrid stays hybrid: no re-capture
+    assert model.precision == "hybrid" and model.graph_epoch == epoch
+    assert model.reply_margin > 10 * margin_soft
+    assert abs(float(model._reply_margin_dev.item()) - model.reply_margin) <= 1e-6 * model.reply_margin
+    eng.reset()
+    _random_playouts(eng, target, picks)
+    eng.search(sims)
+    assert all(eng._graphs.get(k) is g for k, g in graphs.items())   # the graphs captured on the soft net were replayed
+    got, fb_got = eng.root_children(), model.fallback_boards() - fb_soft
+    eng.close()
+
+    fresh = ChessModel(weights=sharp, precision="hybrid")
+    fresh.HYBRID_MIN_BOARDS = 0
+    assert fresh.reply_margin == model.reply_margin
+    ref = LockstepEngine(fresh, G, sims, use_graph=False)
+    ref.reset()
+    _random_playouts(ref, target, picks)
+    ref.search(sims)
+    want, fb_want = ref.root_children(), fresh.fallback_boards()
+    ref.close()
+    print("reload under a captured graph: margin %.2e -> %.2e; boards evaluated twice: soft %d, sharp %d (eager %d)"
+          % (margin_soft, model.reply_margin, fb_soft, fb_got, fb_want))
+    assert fb_got == fb_want and fb_want > 2 * max(fb_soft, 1)
+    for k in ("nchild", "visits", "replies", "moves"):
+        assert np.array_equal(got[k], want[k]), k
+    assert np.array_equal(got["values"].view(np.uint64), want["values"].view(np.uint64))
+    assert np.array_equal(got["priors"].view(np.uint32), want["priors"].view(np.uint32))
 
 
 def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
@@ -201,11 +334,7 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
         model.HYBRID_MIN_BOARDS = 0                                  # (batches this small would run plain f16x3)
         eng = LockstepEngine(model, G, sims)
         eng.reset()
-        for ply in range(int(target.max())):                         # the same random playouts for every mode
-            moves, counts = eng.ctx.legal_moves()
-            pick = (picks[ply] * np.maximum(counts, 1)).astype(np.int64)
-            mv = np.where((target > ply) & (counts > 0), moves[np.arange(G), pick], 0xFFFF).astype(np.uint16)
-            eng.ctx.push_moves(mv)
+        _random_playouts(eng, target, picks)                         # the same random playouts for every mode
         eng.search(sims)
         first = eng.root_children()
         # a second move under the same captured graph (the list's counter must start from zero at every step:
@@ -215,7 +344,7 @@ def test_hybrid_mode_searches_the_trees_of_the_split_precision_mode():
         eng.search(sims)
         if mode == "hybrid":
             lst = model._fallback[G].cpu().numpy()
-            assert 0 <= lst[0] <= G and len(set(lst[2:2 + lst[0]].tolist())) == lst[0]      # one step's list, no repeats
+            assert 0 <= lst[0] <= G and len(set(lst[4:4 + lst[0]].tolist())) == lst[0]      # one step's list, no repeats
         out[mode] = (first, eng.ctx.counters(), model.fallback_boards() if mode == "hybrid" else 0, eng.root_children())
         eng.close()
     for k in (0, 3):
@@ -295,10 +424,10 @@ def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu(disturba
                 assert disturber.poll() is None, "the disturber ended early"
                 assert len(seen) == 1, (blocks, filters, n, mode, len(seen))
             # the indexed split kernels (hybrid mode): every third board listed, onto f16 activations
-            lst = torch.zeros(2 + n, dtype=torch.int32, device="cuda")
+            lst = torch.zeros(_lib.LIST_HEADER + n, dtype=torch.int32, device="cuda")
             pick = torch.arange(0, n, 3, dtype=torch.int32)
             lst[0] = len(pick)
-            lst[2:2 + len(pick)] = pick
+            lst[_lib.LIST_HEADER:_lib.LIST_HEADER + len(pick)] = pick
             _, base = m._run_fused(planes, precision="f16")
             seen = set()
             for _ in range(40):

@@ -97,6 +97,41 @@ def test_results():
     assert g.repetitions() == 5 and g.get_result() == 0                 # fivefold, not threefold
 
 
+# FENs that claim castling rights the position does not hold -> what chess.Board(fen).clean_castling_rights() keeps
+# (python-chess 0.28.3, standard chess: king on e1 / e8 AND an own rook on the corner)
+UNCLEAN_FENS = [
+    ("4k3/p7/8/8/8/8/P7/4K3 w KQkq - 0 1", ""),              # no rooks at all
+    ("4k3/8/8/8/8/8/8/4K2R b KQkq - 0 1", "K"),              # VERDICT r4's example: only h1 holds a rook
+    ("r3k2r/8/8/8/8/8/8/R2K3R w KQkq - 0 1", "kq"),          # white king off e1
+    ("r3k2r/8/8/8/8/8/8/r3K2R w KQkq - 0 1", "Kkq"),         # the a1 rook is BLACK
+    ("r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1", "KQkq"),        # nothing to clean
+    ("4k2r/8/8/8/8/8/8/R3K3 w Qk - 0 1", "Qk"),
+]
+
+
+def _rights(state):
+    return "".join(ch for ch, bit in (("K", 1), ("Q", 2), ("k", 4), ("q", 8)) if (state >> 1) & bit)
+
+
+def test_fen_roots_carry_cleaned_castling_rights_and_repetition_counts_follow():
+    """game.py:17-21 builds ``chess.Board(fen)``; python-chess reads castling rights only through
+    ``clean_castling_rights()`` -- also in the transposition key of ``is_fivefold_repetition`` (game.py:92-109).
+    With the FEN's letters taken as they stand a king's first move would clear bits python-chess never had and
+    the root position would not count as a repetition of its later occurrences."""
+    for fen, want in UNCLEAN_FENS:
+        assert _rights(board_from_fen(fen).state) == want, fen
+    g = OracleGame(board=board_from_fen(UNCLEAN_FENS[0][0]))
+    for rep in range(4):
+        assert g.get_result() is None
+        for u in ["e1d1", "e8d8", "d1e1", "d8e8"]:
+            assert g.move(u)
+    # the root is the first of FIVE occurrences: python-chess ends the game here (16 plies), not 4 plies later
+    assert g.repetitions() == 5 and g.get_result() == 0 and len(g) == 16
+    # castling out of a cleaned root is not generated, out of an intact one it is
+    assert "e1g1" not in OracleGame(board=board_from_fen(UNCLEAN_FENS[2][0])).get_legal_moves()
+    assert "e1g1" in OracleGame(board=board_from_fen(UNCLEAN_FENS[4][0])).get_legal_moves()
+
+
 def test_position_with_the_maximum_number_of_legal_moves():
     """218 legal moves (the published maximum): the size every move / edge array is built for."""
     from tests.util import MAX_MOVES_FEN

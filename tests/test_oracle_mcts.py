@@ -87,7 +87,7 @@ def test_golden_has_a_case_where_numpy_modes_differ(golden_dir):
     assert {c["mode"] for c in cases} == {"nep50", "legacy"}
 
 
-@pytest.mark.parametrize("fixture", ["mcts_cases.json", "mcts_cases_r2.json"])
+@pytest.mark.parametrize("fixture", ["mcts_cases.json", "mcts_cases_r2.json", "mcts_cases_r5.json"])
 def test_oracle_matches_golden_vectors(golden_dir, fixture):
     """mcts_cases_r2.json: roots from FENs (fifty-move claims, mates and stalemates on our move and
     after the reply, fivefold repetition reached by our move, the (previous ply, our move) tuple of
@@ -123,6 +123,17 @@ def test_round2_goldens_reach_the_terminal_paths(golden_dir):
     assert len(cs["max_moves_218"]["visits"]) == 218
     assert cs["quiet_clock_over_90"]["n_terminal_nodes"] > 0
     assert sorted(c["sims"] for c in cs.values())[-2:] == [800, 800]
+
+
+def test_round5_goldens_hold_the_fivefold_of_a_cleaned_fen_root(golden_dir):
+    """mcts_cases_r5.json (FEN roots claiming castling rights the position does not hold): each shuffle tree holds
+    exactly one terminal node -- the move that repeats a position for the fifth time, the ROOT position counted as
+    python-chess counts it (clean_castling_rights in the transposition key); with the FEN's letters hashed as they
+    stand "no_rooks" would hold none."""
+    cs = {c["name"]: c for c in load_cases(golden_dir, "mcts_cases_r5.json") if c["mode"] == "nep50"}
+    assert cs["unclean_rights_no_rooks_fivefold_on_our_move"]["n_terminal_nodes"] == 1
+    assert cs["unclean_rights_one_rook_fivefold_on_our_move"]["n_terminal_nodes"] == 1
+    assert len(cs["unclean_rights_king_off_e1"]["visits"]) == 24      # no white castling among the root's moves
 
 
 @pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not present on this box")
