@@ -164,7 +164,8 @@ def check(lines):
 
 def main(path):
     L = open(path).read().split("\n")
-    starts = [(i, l.split(":")[0]) for i, l in enumerate(L) if l.startswith("_ZN9crl_tower11k_trunk_x16")]
+    # every kernel of namespace crl_tower with hand-counted asm reads: k_trunk_x16<...> and the layer-wise kernels
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(L) if re.match(r"_ZN9crl_tower\d+k_(trunk_x16|conv256|layer)[A-Za-z0-9_]*:", l)]
     total = 0
     for k, (i, name) in enumerate(starts):
         j = starts[k + 1][0] if k + 1 < len(starts) else len(L)
@@ -172,8 +173,9 @@ def main(path):
         end = [n for n, l in enumerate(seg) if "s_endpgm" in l]
         seg = seg[:end[-1] + 1] if end else seg
         bad, states = check(seg)
-        tmpl = re.search(r"k_trunk_x16I(.*?)EEv", name).group(1).replace("Li", "").replace("E", ",").rstrip(",")
-        print("k_trunk_x16<%s>: %s" % (tmpl, "ok" if not bad else "%d instructions touch a register with a ds_read in flight" % len(bad)))
+        m = re.search(r"\d+(k_[a-z0-9_]+?)I(.*?)EEv", name)
+        tmpl = m.group(2).replace("Li", "").replace("E", ",").rstrip(",")
+        print("%s<%s>: %s" % (m.group(1), tmpl, "ok" if not bad else "%d instructions touch a register with a ds_read in flight" % len(bad)))
         for n, l in bad[:8]:
             print("      line %d: %s" % (n, l[:90]))
         total += len(bad)
