@@ -55,7 +55,7 @@ SYMBOLS = [
     "crl_advance", "crl_counters", "crl_trunk_forward",
     "crl_trunk_forward_bitplanes", "crl_trunk_forward_x", "crl_trunk_set_small_batch", "crl_trunk_kernel_name", "crl_heads_forward",
     "crl_heads_forward_legal", "crl_heads_forward_legal_raw", "crl_heads_raw_supported", "crl_heads_set_sliced_max",
-    "crl_set_policy_stats", "crl_abi_version", "crl_source_hash", "crl_reply_margin", "crl_trunk_forward_indexed",
+    "crl_set_policy_stats", "crl_abi_version", "crl_source_hash", "crl_reply_margin", "crl_trunk_forward_indexed", "crl_trunk_workspace_bytes",
     "crl_end_move_fetch", "crl_advance_fetch",
     "crl_im2col3x3_f32", "crl_col2im3x3_f32",
 ]
@@ -202,10 +202,12 @@ def lib():
     L.crl_advance_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
-    L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.crl_trunk_workspace_bytes.argtypes = [i32, i32, i32]
+    L.crl_trunk_workspace_bytes.restype = ctypes.c_size_t
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_reply_margin.argtypes = [vp, vp, vp, i32, vp, i32, vp]
-    L.crl_trunk_forward_indexed.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.crl_trunk_forward_indexed.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]
     L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]

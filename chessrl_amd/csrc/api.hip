@@ -3,6 +3,7 @@
 #include "../../include/chessrl_hip.h"
 #include "search.hpp"
 #include "tower_x16.hpp"
+#include "tower_layer.hpp"
 #include "heads.hpp"
 #include "train_ops.hpp"
 
@@ -646,10 +647,65 @@ static TrunkPick trunk_pick(int filters, int n_boards, bool split)
     return { nb, filters == 64 ? 0 : 1, (filters == 64 && nb == 4) ? 1 : 0 };
 }
 
+// The layer-wise split-precision trunk of 256 filters (csrc/tower_layer.hpp): one launch that expands the input planes into
+// the first activation image, then one launch per convolution, ping-ponging between the two halves of the caller's workspace
+// (crl_trunk_workspace_bytes); the second convolution of a block rewrites the block's input in place.
+static bool trunk_is_layerwise(int filters, int flags)
+{
+    return filters == 256 && (flags & CRL_TRUNK_SPLIT);
+}
+
+static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
+                               int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
+                               void *workspace, const int32_t *list)
+{
+    typedef crl_tower::LayerGeo G;
+    if (!workspace || n_blocks < 1 || !head_out)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the layer-wise 256-filter split-precision trunk needs its "
+                                           "workspace (crl_trunk_workspace_bytes), at least one residual block and head_out");
+    const int n_wg = n_boards / 4;
+    unsigned char *A = (unsigned char *)workspace, *B = A + (size_t)n_wg * G::ACT_WG_BYTES;
+    typedef void (*conv_t)(const unsigned char *, const unsigned char *, const float *, unsigned char *, const int *,
+                           const float *, const float *, float *, float *);
+    typedef void (*expand_t)(const unsigned char *, unsigned char *, const int *);
+    const expand_t ex = list ? (bits ? (expand_t)crl_tower::k_layer_expand<1, 1> : (expand_t)crl_tower::k_layer_expand<0, 1>)
+                             : (bits ? (expand_t)crl_tower::k_layer_expand<1, 0> : (expand_t)crl_tower::k_layer_expand<0, 0>);
+    const conv_t stem = list ? (conv_t)crl_tower::k_layer_conv<4, 0, 1> : (conv_t)crl_tower::k_layer_conv<4, 0, 0>;
+    const conv_t c1 = list ? (conv_t)crl_tower::k_layer_conv<8, 1, 1> : (conv_t)crl_tower::k_layer_conv<8, 1, 0>;
+    const conv_t c2 = list ? (conv_t)crl_tower::k_layer_conv<8, 2, 1> : (conv_t)crl_tower::k_layer_conv<8, 2, 0>;
+    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1> : (conv_t)crl_tower::k_layer_conv<8, 3, 0>;
+    for (conv_t k : { stem, c1, c2, c3 }) {
+        hipError_t ea = allow_big_lds((const void *)k, G::LDS_BYTES);
+        if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
+    }
+    const unsigned char *w = (const unsigned char *)wts;
+    const float *b = (const float *)bias;
+    const int *lst = (const int *)list;
+    hipLaunchKernelGGL(ex, dim3(n_wg), dim3(512), 0, st, (const unsigned char *)planes, B, lst);
+    auto conv = [&](conv_t k, const unsigned char *in, unsigned char *outp, int conv_index, bool last) {
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, st, in, w, b + (size_t)conv_index * G::F, outp, lst,
+                           (const float *)head_w, (const float *)head_b, last ? (float *)head_out : nullptr,
+                           last ? (float *)out_f32 : nullptr);
+    };
+    conv(stem, B, A, 0, false);
+    w += G::conv_bytes(4);
+    for (int blk = 0; blk < n_blocks; blk++) {
+        conv(c1, A, B, 1 + 2 * blk, false);
+        w += G::conv_bytes(8);
+        const bool last = blk + 1 == n_blocks;
+        conv(last ? c3 : c2, B, A, 2 + 2 * blk, last);
+        w += G::conv_bytes(8);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, int flags,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
-                         const void *dev_head_b_f32, void *dev_head_out_f32, const int32_t *dev_index = nullptr)
+                         const void *dev_head_b_f32, void *dev_head_out_f32, const int32_t *dev_index = nullptr,
+                         void *dev_workspace = nullptr)
 {
     if (filters != 64 && filters != 128 && filters != 256)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 64, 128 and 256 filters");
@@ -664,6 +720,10 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     kern_t kern = nullptr;
     int lds_bytes = 0;
     const bool bits = flags & CRL_TRUNK_BITPLANES, split = flags & CRL_TRUNK_SPLIT;
+    if (trunk_is_layerwise(filters, flags))
+        return layer_trunk_forward((hipStream_t)hip_stream, bits, dev_planes_f16, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
+                                   n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32, dev_workspace,
+                                   dev_index);
     const TrunkPick pk = trunk_pick(filters, n_boards, split);
 #define CRL_X16(F_, NB_, PAIR_, GROUP_, SPLIT_)                                                  \
     if (filters == F_ && pk.nb == NB_ && pk.pair == PAIR_ && pk.group == GROUP_ && split == (SPLIT_ != 0)) { \
@@ -674,7 +734,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     CRL_X16(256, 1, 1, 0, 0) CRL_X16(256, 2, 1, 0, 0)
     CRL_X16(64, 2, 0, 0, 0) CRL_X16(64, 4, 0, 1, 0)
     CRL_X16(128, 2, 1, 0, 0) CRL_X16(128, 4, 1, 0, 0)
-    CRL_X16(256, 1, 0, 0, 1) CRL_X16(128, 2, 1, 0, 1) CRL_X16(64, 2, 0, 0, 1) CRL_X16(64, 4, 0, 0, 1)
+    CRL_X16(128, 2, 1, 0, 1) CRL_X16(64, 2, 0, 0, 1) CRL_X16(64, 4, 0, 0, 1)       // (256 filters: tower_layer.hpp)
 #undef CRL_X16
     if (dev_index) {
         // the list form (hybrid precision: the boards the single-MFMA pass could not decide): the split kernels
@@ -682,7 +742,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
         kern = nullptr;
 #define CRL_X16I(F_, NB_, PAIR_)                                                                   \
         if (filters == F_ && pk.nb == NB_) kern = crl_tower::k_trunk_x16<F_, NB_, 1, 0, PAIR_, 0, 1, 1>;
-        CRL_X16I(256, 1, 0) CRL_X16I(128, 2, 1) CRL_X16I(64, 2, 0) CRL_X16I(64, 4, 0)
+        CRL_X16I(128, 2, 1) CRL_X16I(64, 2, 0) CRL_X16I(64, 4, 0)
 #undef CRL_X16I
         dev_out_f32 = const_cast<int32_t *>(dev_index);
     }
@@ -703,12 +763,18 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
 int crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
                               const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
                               const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
-                              const int32_t *dev_list)
+                              const int32_t *dev_list, void *dev_workspace)
 {
     if (!dev_list) return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward_indexed: bad argument");
     return trunk_forward(hip_stream, filters, dev_bitplanes_u64, CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT, dev_wtiles_f16x3,
                          dev_bias_f32, nullptr, n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32,
-                         dev_list);
+                         dev_list, dev_workspace);
+}
+
+size_t crl_trunk_workspace_bytes(int filters, int n_boards, int flags)
+{
+    if (!trunk_is_layerwise(filters, flags) || n_boards < 1) return 0;
+    return (size_t)2 * ((n_boards + 3) / 4) * crl_tower::LayerGeo::ACT_WG_BYTES;
 }
 
 int crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
@@ -733,6 +799,12 @@ int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int b
     if ((filters != 64 && filters != 128 && filters != 256) || n_boards < 4 || !buf || buf_len < 1 ||
         (flags & ~(CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT)))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_kernel_name: bad argument");
+    if (trunk_is_layerwise(filters, flags)) {
+        // one forward = k_layer_expand + the stem + 2 launches per block; the block convolutions dominate
+        snprintf(buf, (size_t)buf_len, "k_layer_conv<8, 1|2|3, 0> (+ k_layer_conv<4, 0, 0>, k_layer_expand<%d, 0>)",
+                 (flags & CRL_TRUNK_BITPLANES) ? 1 : 0);
+        return CRL_OK;
+    }
     const TrunkPick pk = trunk_pick(filters, n_boards, flags & CRL_TRUNK_SPLIT);
     snprintf(buf, (size_t)buf_len, "k_trunk_x16<%d, %d, %d, 0, %d, %d, %d, 0>", filters, pk.nb,
              (flags & CRL_TRUNK_BITPLANES) ? 1 : 0, pk.pair, pk.group, (flags & CRL_TRUNK_SPLIT) ? 1 : 0);
@@ -742,10 +814,10 @@ int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int b
 int crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
                         const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                         int n_boards, int n_blocks, const void *dev_head_w_f32,
-                        const void *dev_head_b_f32, void *dev_head_out_f32)
+                        const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace)
 {
     return trunk_forward(hip_stream, filters, dev_planes, flags, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
-                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32);
+                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32, nullptr, dev_workspace);
 }
 
 int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,

@@ -1,0 +1,469 @@
+// tower_layer.hpp -- the split-precision trunk ("f16x3": operands carried as hi + lo fp16 pairs, products hi.Whi + lo.Whi
+// + hi.Wlo; design of the arithmetic: tower_x16.hpp) at 256 filters as LAYER-WISE kernels (round 5).
+//
+// Replaces, at 256 filters, the trunk of ChessModel (/root/reference/src/chessrl/model.py:33-37,111-122: stem Conv3x3 + N x
+// [Conv3x3-BN-ReLU-Conv3x3-BN-add-ReLU], BN folded on the host) where it has to be fp32-grade: the compliant precision modes
+// of chessrl_amd/model.py (S2 of every simulation in "hybrid", everything in "f16x3").
+//
+// Why not the fused kernel.  k_trunk_x16 keeps the activations of its boards resident in LDS for the whole tower.  At 256
+// filters x (hi, lo) a board is 66 KB: ONE board per workgroup, so every workgroup streams the whole weight set for one board --
+// 171 B of weights through the LDS port per MFMA, 393 GB of L2 -> LDS traffic per launch at 20 x 256 and 4096 boards, 0.446 of
+// the MFMA peak in issued FLOPs (profiles/r04).  Here the activations go back to HBM between layers (268 MB per layer and
+// direction at 4096 boards: 0.1 ms at the chip's rate, spread under 0.55 ms of MFMA work) and a workgroup owns FOUR boards x all
+// 256 output channels and streams BOTH operands:
+//   * the input activations arrive per 32-channel K-chunk, [256 rows = 4 boards x 64 positions][hi 32 | lo 32] fp16 = 32 KiB,
+//     by LDS-DMA from the global activation image into one of two LDS chunk buffers; all 9 taps of the chunk are served from it
+//     (tap (dy,dx) = row p + 8dy + dx, off-board neighbours read a zero row with the same bank residue);
+//   * the weights arrive as 16-KiB planes [256 rows][64 B] (Whi and Wlo of one (chunk, tap)) through a ring of four: 32 KiB of
+//     weights per 768 MFMAs of the workgroup = 43 B per MFMA;
+//   * a wave owns one board x 128 output channels: 4 x 8 accumulator blocks of 16 positions x 16 channels = 128 registers
+//     (no skip stream in registers: it is the block's input, re-read from the activation image by the second convolution's
+//     epilogue as hi + lo -- exact in fp32); per (chunk, tap) 4 + 4 activation and 8 + 8 weight fragment reads feed 96 MFMAs:
+//     0.25 ds_read_b128 per MFMA (k_trunk_x16: 0.5);
+//   * ONE barrier per (chunk, tap) = per 96 MFMAs of a wave: it sits where both weight planes of the tap are consumed into
+//     registers, publishes the next tap's two planes (requested one tap earlier) and frees the two slots for the tap after;
+//   * the epilogue writes hi / lo back to the global image in the layout the next layer's DMA wants:
+//     [workgroup][chunk 8][row 256][hi 32 | lo 32]; the last layer also reduces the three 1x1 head convolutions.
+// One launch per convolution (41 at 20 blocks) + one that expands the input planes: a kernel boundary costs ~2 us of a
+// ~600-us layer, and it is the coherence point between a layer's stores and the next layer's loads; a persistent launch
+// would have to hand-roll that and gains nothing (each workgroup's next layer depends on its own stores having landed).
+// Measured (tools/ubench/conv_layer.hip, 4096 boards, one 256 -> 256 convolution incl. activation read + write): the loop
+// alone 0.526 ms = 0.705 of the MFMA peak in issued FLOPs; first / second convolution of a block 0.57 / 0.62 ms
+// (k_trunk_x16<256, 1, SPLIT>: 0.82 ms per convolution).
+// Accumulation order per output: chunk-major, tap, (hi.Whi, lo.Whi, hi.Wlo) -- NOT the order of k_trunk_x16 (tap-major): the
+// library runs ONE arithmetic per (filters, mode), so at 256 filters every split-precision evaluation -- any batch size, the
+// indexed fall-back launch of the hybrid mode too -- goes through these kernels.
+#pragma once
+#include "tower_x16.hpp"
+
+namespace crl_tower {
+
+struct LayerGeo {
+    static constexpr int F = 256, NB = 4, ROWS = NB * 64, TAPS = 9;
+    static constexpr int GROW = 128;                     // bytes of a row in the global image: hi 32 | lo 32 halves
+    static constexpr int AROW = 160;                     // ... in LDS: + 32 B pad = 10 sixteen-byte units: the 16 lanes of a
+                                                         // ds_read_b128 group (8 rows at quarter q, 8 at q + 1) cover all 64 banks
+    static constexpr int ACHUNK = ROWS * AROW;           // 40 KiB
+    static constexpr int ZERO_OFF = 2 * ACHUNK;
+    static constexpr int ZERO_BYTES = 16 * AROW;
+    static constexpr int WRING_OFF = ((ZERO_OFF + ZERO_BYTES + 1023) / 1024) * 1024;
+    static constexpr int TILE = F * 64;                  // one weight plane: [256 rows][64 B]
+    static constexpr int LDS_BYTES = WRING_OFF + 4 * TILE;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int CHUNK_BYTES = ROWS * GROW;      // one K-chunk of a workgroup's activations in the global image
+    static constexpr int ACT_WG_BYTES = (F / 32) * CHUNK_BYTES;   // 256 KiB of (hi, lo) activations per workgroup and layer
+    static constexpr size_t conv_bytes(int chunks) { return (size_t)chunks * TAPS * 2 * TILE; }   // weight planes of one conv
+};
+
+// uniform 64-bit base in SGPRs + unsigned 32-bit lane offset (through readfirstlane so that hipcc does not fold the lane
+// offset into per-plane 64-bit lane addresses that it then hoists and spills)
+__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const unsigned char *>(((unsigned long long)hi << 32) | lo);
+}
+
+// stage weight plane T of the stream (global image = LDS image, contiguous) into ring slot `slot`: 2 pieces of 1 KiB per
+// wave; woff[j] = the lane's byte offset inside the plane for piece j
+__device__ __forceinline__ void layer_stage_w(const unsigned char *wts, lds_byte *lds, int T, int slot, const unsigned (&woff)[2], int wave_u)
+{
+    const unsigned char *src = uniform_ptr(wts + (size_t)T * LayerGeo::TILE);
+    const int dst0 = LayerGeo::WRING_OFF + slot * LayerGeo::TILE + wave_u * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + woff[j]),
+                                         (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
+}
+
+// piece j (0..4) of activation chunk `chunk` into LDS chunk buffer `buf`: wave w moves rows 32 w .. 32 w + 31 (5 KiB of the
+// padded image = 5 pieces of 1 KiB; lanes that fall on a row's padding re-read its first 16 bytes)
+__device__ __forceinline__ void layer_stage_act(const unsigned char *act, lds_byte *lds, int chunk, int buf, int j,
+                                                unsigned voff, int wave_u)
+{
+    const unsigned char *src = uniform_ptr(act + (size_t)chunk * LayerGeo::CHUNK_BYTES);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff),
+                                     (__attribute__((address_space(3))) void *)(lds + buf * LayerGeo::ACHUNK + wave_u * 5120 + j * 1024),
+                                     16, 0, 0);
+}
+
+// The input planes of the listed / all boards as the first layer's activation image: [workgroup][chunk 4][row 256][hi 32 | lo
+// 32], hi = the 0/1 plane values, lo = 0 (the stem then runs the same three products as every other layer; the one against
+// lo adds exact zeros -- 1/123 of the tower's MFMAs for one kernel body less).
+//   planes  BITS: 128 plane bitboards per board (u64 [n][128], bit sq of plane c = channel c on square sq; row 0 of the planes
+//           is rank 8);  else fp16 [n][64][128]
+//   list    IDX: int32 [LIST_HEADER + n], [0] = listed boards, [LIST_HEADER + k] = the board workgroup k / 4 holds at slot k % 4
+//           (a list that does not fill its last workgroup is padded with its last entry)
+template <int BITS, int IDX>
+__global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__restrict__ planes, unsigned char *__restrict__ act_out,
+                                                      const int *__restrict__ list)
+{
+    typedef LayerGeo G;
+    const int tid = threadIdx.x;
+    int rows[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) rows[b] = blockIdx.x * 4 + b;
+    if constexpr (IDX) {
+        const int listed = list[0];
+        if ((int)blockIdx.x * 4 >= listed) return;
+#pragma unroll
+        for (int b = 0; b < 4; b++) rows[b] = list[LIST_HEADER + (rows[b] < listed ? rows[b] : listed - 1)];
+    }
+    unsigned char *out = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int item = k * 512 + tid;                 // (board, position, 16 channels)
+        const int b = item >> 9, p = (item >> 3) & 63, c = item & 7;
+        int row = rows[0];
+#pragma unroll
+        for (int bb = 1; bb < 4; bb++) row = b == bb ? rows[bb] : row;
+        u32x4 v0, v1;
+        if constexpr (BITS) {
+            const int sq = p ^ 56;
+            const unsigned long long *m = reinterpret_cast<const unsigned long long *>(planes) + (size_t)row * 128 + c * 16;
+            unsigned int w[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                w[e] = (((m[2 * e] >> sq) & 1) ? 0x3C00u : 0u) | (((m[2 * e + 1] >> sq) & 1) ? 0x3C000000u : 0u);
+            v0 = u32x4{w[0], w[1], w[2], w[3]};
+            v1 = u32x4{w[4], w[5], w[6], w[7]};
+        } else {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(planes + ((size_t)row * 64 + p) * 256 + c * 32);
+            v0 = src[0];
+            v1 = src[1];
+        }
+        unsigned char *dst = out + ((size_t)(c >> 1) * G::ROWS + b * 64 + p) * G::GROW + (c & 1) * 32;
+        *reinterpret_cast<u32x4 *>(dst) = v0;
+        *reinterpret_cast<u32x4 *>(dst + 16) = v1;
+        *reinterpret_cast<u32x4 *>(dst + 64) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4 *>(dst + 80) = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+//   act_in   fp16 [n_wg][CHUNKS][256 rows][hi 32 | lo 32]      (row = 64 board + position, board 0..3 of the workgroup)
+//   wts      fp16 planes of THIS convolution [chunk][tap 9][Whi, Wlo][256 rows][4 chunks][8]: rows / 16-byte chunks in the
+//            LDS image's order (Geo16<256,...>::row_channel, wswz)
+//   bias     f32 [256] of this convolution
+//   act_out  [n_wg][8][256][hi 32 | lo 32]; KIND 2, 3: holds the block's input X on entry (the skip connection) and is
+//            rewritten IN PLACE (a lane reads exactly the bytes it then writes)
+// KIND 0: linear (the stem, model.py:33-34: no BN, no activation); 1: ReLU (first convolution of a block); 2: + X, ReLU
+// (second); 3: as 2, and the tail of the tower: the three 1x1 head convolutions reduced to head_out f32 [n][192] (as
+// k_trunk_x16 leaves them) and, if out != nullptr, the trunk's output f32 [n][64][256].
+// IDX: the launch covers the list's boards (k_layer_expand); a workgroup beyond it leaves at once; head_out rows by the list.
+template <int CHUNKS, int KIND, int IDX>
+__global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__restrict__ act_in,
+                                                       const unsigned char *__restrict__ wts,
+                                                       const float *__restrict__ bias,
+                                                       unsigned char *__restrict__ act_out,
+                                                       const int *__restrict__ list,
+                                                       const float *__restrict__ head_w, const float *__restrict__ head_b,
+                                                       float *__restrict__ head_out, float *__restrict__ out)
+{
+    typedef LayerGeo G;
+    typedef Geo16<256, 1, 1> WG;                        // weight plane order (row_channel, wswz, chan_of)
+    static_assert(CHUNKS == 4 || CHUNKS == 8, "128 input planes or 256 channels");
+    constexpr int PT = 4, CT = 8, HC = 4;               // position blocks, channel blocks, channel blocks per half
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
+    lds_byte *lds = (lds_byte *)lds_raw;
+    const int lds_base = (int)(size_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int board = wave >> 1, obase = 128 * (wave & 1);
+    const int r = lane & 15, q = lane >> 4;
+    int listed = 0;
+    if constexpr (IDX) {
+        listed = __builtin_amdgcn_readfirstlane(list[0]);
+        if ((int)blockIdx.x * 4 >= listed) return;     // before any DMA or barrier: the whole workgroup leaves
+    }
+    const unsigned char *act = act_in + (size_t)blockIdx.x * G::ACT_WG_BYTES;     // (the stem's image fills half a slot)
+
+    // per-lane source offsets of the five activation pieces of a chunk
+    unsigned voff[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int g = j * 64 + lane, rl = g / 10, col = g % 10;
+        voff[j] = (unsigned)((wave * 32 + rl) * G::GROW + (col < 8 ? col : 0) * 16);
+    }
+
+    // ---- prologue: chunk 0, the planes of taps 0 and 1, zero rows
+#pragma unroll
+    for (int j = 0; j < 5; j++) layer_stage_act(act, lds, 0, 0, j, voff[j], wave_u);
+    const unsigned woff[2] = {(unsigned)(tid * 16), (unsigned)(8192 + tid * 16)};
+#pragma unroll
+    for (int T = 0; T < 4; T++) layer_stage_w(wts, lds, T, T, woff, wave_u);
+    for (int i = tid; i < G::ZERO_BYTES / 16; i += 512)
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    f32x4v acc[PT][CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + obase + WG::chan_of(ct, 0) + 8 * q);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) acc[pt][ct] = f32x4v{bv[0], bv[1], bv[2], bv[3]};
+    }
+
+    // the lane's activation row in block pt: 64 board + 16 pt + r; neighbours on the board as wave masks
+    const int px = r & 7, py0 = r >> 3;
+    const int base0 = lds_base + (board * 64 + r) * G::AROW + q * 16;
+    const int zero_q = lds_base + G::ZERO_OFF + q * 16;
+    const unsigned long long xm_left = __ballot(px >= 1), xm_right = __ballot(px <= 6);
+    unsigned long long ym_up[PT], ym_down[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; pt++) {
+        ym_up[pt] = __ballot(py0 + 2 * pt >= 1);
+        ym_down[pt] = __ballot(py0 + 2 * pt <= 6);
+    }
+    auto tap_rows = [&](auto TAPC, int buf, int (&dst)[PT]) {
+        constexpr int tap = decltype(TAPC)::value;
+        constexpr int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        constexpr int shift = 8 * dy + dx;
+        // (opaque per call: the addresses of all nine taps are loop invariants, and hipcc would otherwise compute the
+        // 72 of them once in front of the chunk loop and spill them)
+        int bb = base0 + buf * G::ACHUNK, rr = r;
+        asm volatile("" : "+v"(bb), "+v"(rr));
+        const int zrow = zero_q + ((rr + shift) & 15) * G::AROW;
+        const int inb = bb + shift * G::AROW;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            const int row = inb + pt * 16 * G::AROW;
+            if constexpr (dx == 0 && dy == 0) {
+                dst[pt] = row;
+            } else {
+                unsigned long long m;
+                if constexpr (dy == 0) m = dx < 0 ? xm_left : xm_right;
+                else if constexpr (dx == 0) m = dy < 0 ? ym_up[pt] : ym_down[pt];
+                else m = (dx < 0 ? xm_left : xm_right) & (dy < 0 ? ym_up[pt] : ym_down[pt]);
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst[pt]) : "v"(zrow), "v"(row), "s"(m));
+            }
+        }
+    };
+    // weight fragment address: row obase + 16 ct + r of a plane, quarter q (the swizzle does not depend on ct)
+    const int w0 = lds_base + G::WRING_OFF + (obase + r) * 64 + ((q ^ WG::wswz(obase + r)) << 4);
+
+    wait_vmcnt_n<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    half8 x[2][PT], w[2][HC];
+    int ab[PT], abn[PT];
+
+    // fragment reads (inline asm: counted by hand, see tower_common.hpp)
+    auto rd_x = [&](half8 (&dst)[PT], const int (&rows)[PT], auto LO) {
+        constexpr int lo = decltype(LO)::value;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) dst[pt] = lds_read16_asm<lo * 64>(rows[pt]);
+    };
+    auto rd_w = [&](half8 (&dst)[HC], auto SLOT, auto HALF) {
+        constexpr int slot = decltype(SLOT)::value, half = decltype(HALF)::value;
+        static_for<0, HC>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            dst[c] = lds_read16_asm<slot * G::TILE + (half * HC + c) * 1024>(w0);
+        });
+    };
+    auto mfma16 = [&](const half8 (&ww)[HC], const half8 (&xx)[PT], auto HALF) {
+        constexpr int half = decltype(HALF)::value;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int c = 0; c < HC; c++)
+                acc[pt][half * HC + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ww[c], xx[pt], acc[pt][half * HC + c], 0, 0, 0);
+    };
+
+    // cold start: hi rows of (chunk 0, tap 0) and Whi[0:4]
+    tap_rows(I0{}, 0, ab);
+    rd_x(x[0], ab, I0{});
+    rd_w(w[0], I0{}, I0{});
+
+    // One (chunk, tap): u = 9 c + t; parity P = u & 1 (compile time).  At its start the hi fragments sit in x[P] and Whi[0:4]
+    // in w[P]; the Whi plane is in ring slot 2 P, Wlo in 2 P + 1, the next tap's planes in 2 (1 - P), 2 (1 - P) + 1.
+    //        MFMAs (16 each)            fragment reads issued in front of them
+    //   S1  hi x Whi[0:4]  w[P]        w[1-P] <- Whi[4:8]
+    //   S2  hi x Whi[4:8]  w[1-P]      x[1-P] <- lo rows
+    //   S3  lo x Whi[4:8]  w[1-P]
+    //   S4  lo x Whi[0:4]  w[P]        w[1-P] <- Wlo[4:8]
+    //   S5  hi x Wlo[4:8]  w[1-P]      w[P] <- Wlo[0:4];  x[1-P] <- the next tap's hi rows
+    //   -- barrier: both planes of this tap are in registers; the next tap's planes (requested at the previous barrier)
+    //      are published; the planes of the tap after next go into this tap's slots, + one piece of the next chunk
+    //   S6  hi x Wlo[0:4]  w[P]        w[1-P] <- the next tap's Whi[0:4]
+    // per output the order is hi.Whi, lo.Whi, hi.Wlo; the next tap starts with parity 1 - P.  Two fragment buffers of each
+    // kind (64 registers) beside the 128 accumulators.
+    auto tap_body = [&](auto PC, int c, auto TC) {
+        constexpr int P = decltype(PC)::value, t = decltype(TC)::value;
+        typedef std::integral_constant<int, 2 * P> SHI;
+        typedef std::integral_constant<int, 2 * P + 1> SLO;
+        typedef std::integral_constant<int, 2 * (1 - P)> SNEXT;
+        const int u = c * G::TAPS + t;
+        // (no branch in the body: behind the last tap the prefetches read valid LDS that nobody uses, and the DMA requests
+        // re-load the last planes / the last chunk into slots and a buffer that are dead -- a branch around inline-asm
+        // reads would invite phi copies of registers whose data has not landed, tower_x16.hpp)
+        // S1
+        rd_w(w[1 - P], SHI{}, I1{});
+        wait_lgkm_n<HC>();                              // x[P] and w[P] have landed
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[P], x[P], I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        // S2
+        rd_x(x[1 - P], ab, I1{});
+        wait_lgkm_n<PT>();                              // w[1-P] = Whi[4:8]
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[1 - P], x[P], I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        // S3
+        wait_lgkm_n<0>();                               // the lo rows
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[1 - P], x[1 - P], I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        // S4 (+ the next tap's row addresses: VALU work beside the MFMAs)
+        rd_w(w[1 - P], SLO{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[P], x[1 - P], I0{});
+        {
+            constexpr int tn = t + 1 == G::TAPS ? 0 : t + 1;
+            const int cn = t + 1 == G::TAPS ? c + 1 : c;
+            tap_rows(std::integral_constant<int, tn>{}, cn & 1, abn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // S5
+        rd_w(w[P], SLO{}, I0{});
+        rd_x(x[1 - P], abn, I0{});
+        wait_lgkm_n<HC + PT>();                         // w[1-P] = Wlo[4:8]
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[1 - P], x[P], I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        // barrier: every fragment read of this tap's two planes has landed (only the next tap's x may be in flight)
+        wait_lgkm_n<PT>();
+        wait_vmcnt_n<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int un = u + 2 < CHUNKS * G::TAPS ? u + 2 : CHUNKS * G::TAPS - 1;
+            layer_stage_w(wts, lds, 2 * un, 2 * P, woff, wave_u);
+            layer_stage_w(wts, lds, 2 * un + 1, 2 * P + 1, woff, wave_u);
+        }
+        if constexpr (t < 5) {
+            // (the buffer of chunk c + 1 was last read in chunk c - 1, whose last barrier is behind us)
+            const int cn = c + 1 < CHUNKS ? c + 1 : CHUNKS - 1;
+            layer_stage_act(act, lds, cn, (c + 1) & 1, t, voff[t < 5 ? t : 0], wave_u);
+        }
+        // S6
+        rd_w(w[1 - P], SNEXT{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(w[P], x[P], I0{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) ab[pt] = abn[pt];
+    };
+
+    for (int c = 0; c < CHUNKS; c += 2) {
+        static_for<0, G::TAPS>([&](auto TC) {
+            constexpr int t = decltype(TC)::value;
+            tap_body(std::integral_constant<int, t & 1>{}, c, TC);
+        });
+        static_for<0, G::TAPS>([&](auto TC) {
+            constexpr int t = decltype(TC)::value;
+            tap_body(std::integral_constant<int, (1 + t) & 1>{}, c + 1, TC);
+        });
+        // the reads in flight across the back-edge are drained: hipcc cannot see them and is free to copy their registers
+        // there (phi moves) before the data has landed (tower_x16.hpp, tools/check_asm_hazards.py)
+        wait_lgkm_n<0>();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- epilogue: a lane holds, per (pt, g), the 8 consecutive channels obase + 32 g + 8 q .. + 7 of position 16 pt + r
+    unsigned char *outp = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
+    float part[PT][3];                                  // KIND 3: partial sums of the three head convolutions
+    if constexpr (KIND == 3) {
+        // (opaque from here on: the head weights are loop invariants of the epilogue; hipcc would otherwise load all 96 of
+        // a lane's values in front of the tap loop and spill accumulators to keep them)
+        asm volatile("" : "+s"(head_w), "+s"(out));
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) part[pt][k] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < CT / 2; g++)
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++) {
+            // output chunk (obase + 32 g) / 32, row 64 board + 16 pt + r, quarter q
+            unsigned char *dst = outp + ((size_t)((obase >> 5) + g) * G::ROWS + board * 64 + 16 * pt + r) * G::GROW + q * 16;
+            f32x4v o[2] = {acc[pt][2 * g], acc[pt][2 * g + 1]};
+            if constexpr (KIND >= 2) {
+                // the skip connection: the block's input as it stands in the image, hi + lo (exact in fp32)
+                const half8 xh = *reinterpret_cast<const half8 *>(dst), xl = *reinterpret_cast<const half8 *>(dst + 64);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    o[0][j] += (float)xh[j] + (float)xl[j];
+                    o[1][j] += (float)xh[4 + j] + (float)xl[4 + j];
+                }
+            }
+            if constexpr (KIND != 0) {
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[h][j] = fmaxf(o[h][j], 0.f);
+            }
+            if constexpr (KIND == 3) {
+                const int o0 = obase + 32 * g + 8 * q;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4 *>(head_w + k * G::F + o0);
+                    const f32x4 wb = *reinterpret_cast<const f32x4 *>(head_w + k * G::F + o0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) part[pt][k] += o[0][j] * wa[j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) part[pt][k] += o[1][j] * wb[j];
+                }
+                if (!IDX && out) {
+                    float *op = out + (((size_t)blockIdx.x * 4 + board) * 64 + 16 * pt + r) * G::F + o0;
+                    *reinterpret_cast<f32x4 *>(op) = f32x4{o[0][0], o[0][1], o[0][2], o[0][3]};
+                    *reinterpret_cast<f32x4 *>(op + 4) = f32x4{o[1][0], o[1][1], o[1][2], o[1][3]};
+                }
+            } else {
+                half8 hi8, lo8;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    hi8[j] = (_Float16)o[0][j];
+                    hi8[4 + j] = (_Float16)o[1][j];
+                    lo8[j] = (_Float16)(o[0][j] - (float)hi8[j]);
+                    lo8[4 + j] = (_Float16)(o[1][j] - (float)hi8[4 + j]);
+                }
+                *reinterpret_cast<half8 *>(dst) = hi8;
+                *reinterpret_cast<half8 *>(dst + 64) = lo8;
+            }
+        }
+    if constexpr (KIND == 3) {
+        // a position's 256 channels live in 2 waves x 4 lane quarters x ... : 8 partial sums per output, added in a fixed
+        // order (no float atomics: results are reproducible); the LDS is free (every wave is past its last fragment read
+        // once it is past the barrier below)
+        constexpr int NC = 8;
+        __builtin_amdgcn_s_barrier();
+        __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
+#pragma unroll
+        for (int pt = 0; pt < PT; pt++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                scratch[(((board * 64 + 16 * pt + r) * 3) + k) * NC + (wave & 1) * 4 + q] = part[pt][k];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int i = tid; i < G::ROWS * 3; i += 512) {
+            const int k = i % 3, bp = i / 3;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v += scratch[i * NC + c];      // fixed order
+            v += head_b[k];
+            size_t gb = (size_t)blockIdx.x * 4 + (bp >> 6);
+            if constexpr (IDX) {
+                const int kk = (int)blockIdx.x * 4 + (bp >> 6);
+                gb = (size_t)list[LIST_HEADER + (kk < listed ? kk : listed - 1)];
+            }
+            const int pos = bp & 63;
+            head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
+        }
+    }
+}
+
+}  // namespace crl_tower

@@ -265,6 +265,7 @@ class ChessModel(object):
         self.trunk_events = None                 # bench.py: a list -> every trunk launch is bracketed by HIP events
         self.guard = {"checks": 0, "positions": 0, "worst": 0.0, "fired": None}   # guard_check's record
         self._scratch = {}                       # batch size -> slice statistics of the small-batch heads
+        self._workspace = {}                     # batch size -> activation images of the layer-wise trunk (256 filters, f16x3)
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
@@ -363,7 +364,12 @@ class ChessModel(object):
                 # CRL_TRUNK_SPLIT: per tap the planes of Whi, then of Wlo = fp16(W - Whi); the kernel
                 # uses every Whi plane for hi.Whi and lo.Whi in one pass, the Wlo planes for hi.Wlo
                 t_lo = planes_of((k - hi.float()).to(torch.float16))
-                tiles3.append(torch.stack([t_hi, t_lo], dim=1).contiguous().reshape(-1))   # [tap][part][g][row]...
+                if F_ == 256:
+                    # the layer-wise kernels of csrc/tower_layer.hpp keep a 32-channel K-chunk of the activations in
+                    # LDS for all nine taps: planes K-CHUNK-major, [g][tap][part][row]...
+                    tiles3.append(torch.stack([t_hi, t_lo], dim=2).permute(1, 0, 2, 3, 4, 5).contiguous().reshape(-1))
+                else:
+                    tiles3.append(torch.stack([t_hi, t_lo], dim=1).contiguous().reshape(-1))   # [tap][part][g][row]...
             biases.append(b)
         kp, bp = _fold(w, "policy.conv", "policy.bn")          # [2][F][1][1]
         kv, bv = _fold(w, "value.conv", "value.bn")            # [1][F][1][1]
@@ -451,6 +457,7 @@ class ChessModel(object):
                                        "precision=%r): use set_precision() or precision='auto'"
                                        % ("f16x3" if split else "f16", self.precision_requested))
         flags = (_lib.TRUNK_BITPLANES if bits else 0) | (_lib.TRUNK_SPLIT if split else 0)
+        ws = self._trunk_workspace(bp) if split else None
         ev = self._trunk_event("f16x3" if split else "f16")
         rc = _lib.lib().crl_trunk_forward_x(
             ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), self.filters, flags,
@@ -458,12 +465,25 @@ class ChessModel(object):
             ctypes.c_void_p(self._wbias.data_ptr()),
             ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
             ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
-            ctypes.c_void_p(heads.data_ptr()))
+            ctypes.c_void_p(heads.data_ptr()), ctypes.c_void_p(ws.data_ptr() if ws is not None else None))
         if rc != 0:
             raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
         if ev is not None:
             ev[2].record()
         return planes, heads, trunk
+
+    def _trunk_workspace(self, bp):
+        """The activation images the layer-wise split-precision trunk (256 filters; csrc/tower_layer.hpp) ping-pongs
+        between: crl_trunk_workspace_bytes of device memory per batch size, kept (captured graphs hold the address);
+        None where the library wants none."""
+        from . import _lib
+        ws = self._workspace.get(bp)
+        if ws is None:
+            n = int(_lib.lib().crl_trunk_workspace_bytes(self.filters, bp, _lib.TRUNK_BITPLANES | _lib.TRUNK_SPLIT))
+            if n == 0:
+                return None
+            ws = self._workspace[bp] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _trunk_event(self, kind):
         """Measurement hook (bench.py's in-step kernel time): with ``trunk_events`` a list, every trunk launch is
@@ -657,10 +677,12 @@ class ChessModel(object):
                                     vp(lst.data_ptr()))
             if rc != 0:
                 raise _lib.HipLibraryError("crl_reply_margin failed (%d)" % rc)
+            ws = self._trunk_workspace(bp)
             ev = self._trunk_event("f16x3 indexed")
             rc = L.crl_trunk_forward_indexed(stream, self.filters, vp(planes_p.data_ptr()), vp(self._wtiles3.data_ptr()),
                                              vp(self._wbias.data_ptr()), bp, self.blocks, vp(self._head_w.data_ptr()),
-                                             vp(self._head_b.data_ptr()), vp(hp_full.data_ptr()), vp(lst.data_ptr()))
+                                             vp(self._head_b.data_ptr()), vp(hp_full.data_ptr()), vp(lst.data_ptr()),
+                                             vp(ws.data_ptr() if ws is not None else None))
             if rc != 0:
                 raise _lib.HipLibraryError("crl_trunk_forward_indexed failed (%d)" % rc)
             if ev is not None:
@@ -680,6 +702,8 @@ class ChessModel(object):
             self._fallback[bp] = torch.zeros(_lib.LIST_HEADER + bp, dtype=torch.int32, device=self.device)
         if self.fused:
             self._heads_scratch(int(n_boards))
+            if self._trunk_mode() == "f16x3":
+                self._trunk_workspace(bp)
 
     def fallback_boards(self):
         """hybrid: total number of S1 boards evaluated a second time since the model was built (sum over

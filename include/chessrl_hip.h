@@ -21,6 +21,7 @@
 #ifndef CHESSRL_HIP_H
 #define CHESSRL_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -245,7 +246,16 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
 int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
-                         const void *dev_head_b_f32, void *dev_head_out_f32);
+                         const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace);
+
+/* 256 filters with CRL_TRUNK_SPLIT run LAYER-WISE (csrc/tower_layer.hpp: one launch per convolution, a workgroup owns 4
+ * boards x all 256 output channels and streams activations and weights; the fused kernel could keep ONE such board resident
+ * and streamed the whole weight set for it).  The caller lends the activation images: crl_trunk_workspace_bytes() bytes of
+ * device memory (two images of 256 KiB per 4 boards; 0 for every other (filters, flags): dev_workspace may then be NULL),
+ * contents undefined before and after a call.  n_blocks >= 1 and dev_head_out_f32 are required there.  The weight image of
+ * that path lists, per convolution, the planes K-CHUNK-major: [conv][in-ch/32][tap][Whi, Wlo][256 rows][4 chunks][8 in]
+ * (rows / chunks as above; the stem has 4 chunks of input planes, every other convolution 8). */
+size_t crl_trunk_workspace_bytes(int filters, int n_boards, int flags);
 
 /* Hybrid precision (ChessModel(precision="hybrid")).  An evaluation of S1 only chooses the opponent's reply
  * -- argmax of the policy over the legal labels (agentdistributed.py:57-58 -> mctree.py:244-250) -- so S1 runs
@@ -261,14 +271,15 @@ int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *d
  * crl_trunk_forward_indexed evaluates exactly the listed boards (rows of dev_bitplanes_u64 / dev_head_out_f32;
  * other rows of dev_head_out_f32 are left as they are): the CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT kernels with a
  * grid for n_boards whose surplus workgroups exit at once -- the list never leaves the device, the launch sequence
- * is fixed and captures into a hipGraph.  Stateless. */
+ * is fixed and captures into a hipGraph.  dev_workspace: as for crl_trunk_forward_x (crl_trunk_workspace_bytes(filters,
+ * n_boards, CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT); may be the buffer of the full-batch launches).  Stateless. */
 #define CRL_LIST_HEADER 4
 int  crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_t *dev_counts, int n_boards,
                       const float *dev_log_margin_f32, int rows_are_logits, int32_t *dev_list);
 int  crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
                                const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
                                const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
-                               const int32_t *dev_list);
+                               const int32_t *dev_list, void *dev_workspace);
 
 /* crl_trunk_forward with the input given as plane bitboards (CRL_PLANES_BITS), uint64
  * [n_boards][128]; everything else as above. */

@@ -239,9 +239,11 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
             lst[0] = len(pick)
             lst[_lib.LIST_HEADER:_lib.LIST_HEADER + len(pick)] = torch.tensor(pick, dtype=torch.int32)[torch.randperm(len(pick))] if pick else 0
             hp = h16.clone()
+            ws = m._trunk_workspace(n)                               # 256 filters: the layer-wise kernels' activation images
             assert L.crl_trunk_forward_indexed(st, filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
                                                vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()),
-                                               vp(m._head_b.data_ptr()), vp(hp.data_ptr()), vp(lst.data_ptr())) == 0
+                                               vp(m._head_b.data_ptr()), vp(hp.data_ptr()), vp(lst.data_ptr()),
+                                               vp(ws.data_ptr() if ws is not None else None)) == 0
             torch.cuda.synchronize()
             mask = torch.zeros(n, dtype=torch.bool, device="cuda")
             mask[pick] = True
@@ -435,7 +437,8 @@ def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu(disturba
                 assert _lib.lib().crl_trunk_forward_indexed(
                     vp(torch.cuda.current_stream().cuda_stream), filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
                     vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()), vp(m._head_b.data_ptr()),
-                    vp(hp.data_ptr()), vp(lst.data_ptr())) == 0
+                    vp(hp.data_ptr()), vp(lst.data_ptr()),
+                    vp(m._trunk_workspace(n).data_ptr() if m._trunk_workspace(n) is not None else None)) == 0
                 torch.cuda.synchronize()
                 seen.add(hashlib.md5(hp.cpu().numpy().tobytes()).hexdigest())
             assert len(seen) == 1, (blocks, filters, n, "indexed", len(seen))

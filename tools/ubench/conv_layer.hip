@@ -3,10 +3,11 @@
 // CPU evaluation of sampled outputs; timed as: loop alone (MODE 0), conv1 of a block (MODE 1: ReLU, hi/lo written),
 // conv2 (MODE 2: + fp32 skip read, ReLU, hi/lo + skip written).  Stop rule: build into the product only if a layer
 // takes <= 0.62 ms at 4096 boards (25 ms per 41-conv tower; k_trunk_x16<256,1,SPLIT> = 33.7 ms).
+// The kernel is the product's (chessrl_amd/csrc/tower_layer.hpp: k_layer_conv<8, 1 | 2, 0>).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I chessrl_amd/csrc tools/ubench/conv_layer.hip -o tools/ubench/conv_layer
 //   ./conv_layer [boards=4096] [reps=20]
 #define CRL_HARNESS 1
-#include "conv_layer.hpp"
+#include "tower_layer.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +21,7 @@ static uint32_t rng_state = 12345;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 static float frnd(float s) { return ((int)(rnd() % 2001) - 1000) * 1e-3f * s; }
 
-typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, unsigned char *, const float *, float *);
+typedef void (*kern_t)(const unsigned char *, const unsigned char *, const float *, unsigned char *, const int *, const float *, const float *, float *, float *);
 
 int main(int argc, char **argv)
 {
@@ -43,7 +44,7 @@ int main(int argc, char **argv)
                     act[at + 32 + e] = (_Float16)(v - (float)hi);
                 }
     // weights in image order [chunk][tap][part][row][phys 16-B chunk][8]
-    std::vector<_Float16> wimg((size_t)G::TILES_PER_CONV * G::TILE / 2);
+    std::vector<_Float16> wimg(G::conv_bytes(8) / 2);
     std::vector<float> W((size_t)256 * 256 * 9), Whi(W.size()), Wlo(W.size());      // [o][cin][tap]
     const float scale = 1.5f / sqrtf(9.0f * 256);
     for (auto &w : W) w = frnd(scale);
@@ -59,47 +60,52 @@ int main(int argc, char **argv)
                             const float v = (part ? Wlo : Whi)[((size_t)o * 256 + cin) * 9 + t];
                             wimg[((((size_t)(c * 9 + t) * 2 + part) * 256 + row) * 4 + phys) * 8 + e] = (_Float16)v;
                         }
-    std::vector<float> bias(256), skip((size_t)n_wg * 256 * 256);
+    std::vector<float> bias(256);
     for (auto &b : bias) b = frnd(0.1f);
-    for (auto &s : skip) s = fabsf(frnd(1.0f));
+    // the block's input X (KIND 2 reads it from the OUTPUT image and rewrites it in place): another image like `act`
+    std::vector<_Float16> xin(act_halves);
+    for (size_t i = 0; i < act_halves; i += 64)
+        for (int e = 0; e < 32; e++) {
+            const float v = fabsf(frnd(1.0f));
+            xin[i + e] = (_Float16)v;
+            xin[i + 32 + e] = (_Float16)(v - (float)xin[i + e]);
+        }
 
-    unsigned char *d_act, *d_out, *d_w; float *d_bias, *d_skip, *d_skip_out;
+    unsigned char *d_act, *d_out, *d_w; float *d_bias;
     CK(hipMalloc(&d_act, act_halves * 2)); CK(hipMemcpy(d_act, act.data(), act_halves * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_out, act_halves * 2)); CK(hipMemset(d_out, 0, act_halves * 2));
     CK(hipMalloc(&d_w, wimg.size() * 2)); CK(hipMemcpy(d_w, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_bias, 1024)); CK(hipMemcpy(d_bias, bias.data(), 1024, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_skip, skip.size() * 4)); CK(hipMemcpy(d_skip, skip.data(), skip.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_skip_out, skip.size() * 4));
 
     const double flops_alg = 2.0 * 64 * 9 * 256.0 * 256.0 * boards, flops_issued = 3.0 * flops_alg;
     std::vector<_Float16> out(act_halves);
-    std::vector<float> skip_out(skip.size());
     for (int mode = 0; mode <= 2; mode++) {
-        kern_t k = mode == 0 ? (kern_t)k_conv256_split<0> : (mode == 1 ? (kern_t)k_conv256_split<1> : (kern_t)k_conv256_split<2>);
+        kern_t k = mode == 0 ? (kern_t)k_layer_conv<8, 0, 0> : (mode == 1 ? (kern_t)k_layer_conv<8, 1, 0> : (kern_t)k_layer_conv<8, 2, 0>);
         CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         double best = 1e9;
         for (int round = 0; round < 3; round++) {
             for (int i = 0; i < 2; i++)
-                hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, d_skip, d_skip_out);
+                hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, nullptr);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
             for (int i = 0; i < reps; i++)
-                hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, d_skip, d_skip_out);
+                hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, nullptr);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms / reps < best) best = ms / reps;
         }
         CK(hipGetLastError());
-        printf("conv 256->256 split, %d boards, MODE %d (%s): %8.4f ms  issued %7.1f TFLOP/s = %.3f of 2.5 PF, algorithmic %.3f  [stop rule: <= 0.62 ms]\n",
-               boards, mode, mode == 0 ? "loop alone" : (mode == 1 ? "conv1: ReLU, hi/lo out" : "conv2: + skip in, hi/lo + skip out"),
+        printf("conv 256->256 split, %d boards, KIND %d (%s): %8.4f ms  issued %7.1f TFLOP/s = %.3f of 2.5 PF, algorithmic %.3f  [stop rule: <= 0.62 ms]\n",
+               boards, mode, mode == 0 ? "linear, hi/lo out" : (mode == 1 ? "conv1: ReLU, hi/lo out" : "conv2: + X (hi + lo) in, ReLU, in place"),
                best, flops_issued / best / 1e9, flops_issued / best / 1e9 / 2500.0, flops_alg / best / 1e9 / 2500.0);
         fflush(stdout);
-        if (mode == 0) continue;
         // ---- check sampled outputs against a CPU evaluation (double accumulation of the same three products)
+        CK(hipMemcpy(d_out, xin.data(), act_halves * 2, hipMemcpyHostToDevice));      // X (only KIND 2 reads it)
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+        CK(hipDeviceSynchronize());
         CK(hipMemcpy(out.data(), d_out, act_halves * 2, hipMemcpyDeviceToHost));
-        if (mode == 2) CK(hipMemcpy(skip_out.data(), d_skip_out, skip.size() * 4, hipMemcpyDeviceToHost));
-        double worst = 0, worst_skip = 0; int bad = 0;
+        double worst = 0; int bad = 0;
         for (int s = 0; s < 3000; s++) {
             const int wg = s < 1000 ? (s & 1 ? n_wg - 1 : 0) : rnd() % n_wg;
             const int b = rnd() % 4, p = s < 64 ? s : rnd() % 64, o = rnd() % 256;
@@ -115,21 +121,15 @@ int main(int argc, char **argv)
                     sum += hi * Whi[wi] + lo * Whi[wi] + hi * Wlo[wi];
                 }
             }
-            if (mode == 2) sum += skip[((size_t)wg * 256 + b * 64 + p) * 256 + o];
-            const double want = sum > 0 ? sum : 0;
             const size_t at = (((size_t)wg * 8 + (o >> 5)) * 256 + b * 64 + p) * 64 + (o & 31);
+            if (mode == 2) sum += (double)(float)xin[at] + (double)(float)xin[at + 32];
+            const double want = mode == 0 ? sum : (sum > 0 ? sum : 0);
             const double got = (double)(float)out[at] + (double)(float)out[at + 32];
             const double err = fabs(got - want);
             if (err > worst) worst = err;
             if (err > 2e-5 * (1.0 + fabs(want))) bad++;
-            if (mode == 2) {
-                const double e2 = fabs((double)skip_out[((size_t)wg * 256 + b * 64 + p) * 256 + o] - want);
-                if (e2 > worst_skip) worst_skip = e2;
-                if (e2 > 2e-5 * (1.0 + fabs(want))) bad++;
-            }
         }
-        printf("    check: 3000 sampled outputs vs CPU: max |err| %.3g (hi+lo)%s, %d beyond 2e-5 relative -> %s\n", worst,
-               mode == 2 ? (std::string(", skip ") + std::to_string(worst_skip)).c_str() : "", bad, bad ? "WRONG" : "ok");
+        printf("    check: 3000 sampled outputs vs CPU: max |err| %.3g (hi + lo), %d beyond 2e-5 relative -> %s\n", worst, bad, bad ? "WRONG" : "ok");
         fflush(stdout);
     }
     return 0;
