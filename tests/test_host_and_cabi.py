@@ -351,6 +351,30 @@ def test_trunk_weight_image_is_the_plane_order_the_header_documents():
             assert planes[tap, part, g, r, c ^ ((-(r >> 2)) & 3), e] == want, (conv, tap, part, g, r, c, e)
         assert np.abs(hi + lo - k).max() <= 2.0 ** -20 * np.abs(k).max()
         off += len(parts) * 9 * cin * F_
+    # 256 filters: the split-precision image of the LAYER-WISE kernels (csrc/tower_layer.hpp), K-chunk-major:
+    # [conv][in-ch/32][tap][Whi, Wlo][256 rows][4 chunks][8 in] (include/chessrl_hip.h: crl_trunk_workspace_bytes)
+    F_ = 256
+    w = tower_oracle.init_weights(1, F_, seed=5, randomize_bn=True)
+    m = M.ChessModel.__new__(M.ChessModel)
+    m.filters, m.blocks, m.device = F_, 1, torch.device("cpu")
+    m.precision_requested = "f16x3"
+    m._pack_fused(w)
+    img3 = m._wtiles3.float().numpy()
+    assert img3.size == 2 * (9 * 128 * F_ + 2 * 9 * F_ * F_)
+    off = 0
+    for conv, bn in convs:
+        k = M._fold(w, conv, bn)[0].numpy()
+        hi = k.astype(np.float16).astype(np.float32)
+        parts = [hi, (k - hi).astype(np.float16).astype(np.float32)]
+        cin = 128 if conv == "stem" else F_
+        planes = img3[off:off + 2 * 9 * cin * F_].reshape(cin // 32, 9, 2, F_, 4, 8)
+        for _ in range(400):
+            g, tap, part, r, c, e = (int(rng.integers(n)) for n in (cin // 32, 9, 2, F_, 4, 8))
+            chan = (r & ~31) + 8 * ((r & 15) >> 2) + 4 * ((r >> 4) & 1) + (r & 3)
+            i = 32 * g + 8 * c + e
+            want = parts[part][chan, i, tap // 3, tap % 3] if i < k.shape[1] else 0.0
+            assert planes[g, tap, part, r, c ^ ((-(r >> 2)) & 3), e] == want, (conv, g, tap, part, r, c, e)
+        off += 2 * 9 * cin * F_
 
 
 @pytest.fixture(scope="module")
@@ -381,8 +405,9 @@ def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(device_a
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py"), device_asm],
                        capture_output=True, text=True)
-    kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
-    assert len(kernels) >= 20, r.stdout                       # every dispatched (F, NB, BITS, PAIR, GROUP, SPLIT)
+    kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
+    # every dispatched k_trunk_x16<F, NB, BITS, PAIR, GROUP, SPLIT, IDX> + the layer-wise k_layer_conv<CHUNKS, KIND, IDX>
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) == 8, r.stdout
     assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
 
 
@@ -409,26 +434,32 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lds_race_check.py"), device_asm, "2"],
                        capture_output=True, text=True)
-    kernels = [l for l in r.stdout.splitlines() if l.startswith("k_trunk_x16<")]
-    assert len(kernels) >= 20, r.stdout + r.stderr
+    kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
+    # (round 5: also the layer-wise convolution kernels of csrc/tower_layer.hpp, one whole convolution each: 72 taps,
+    # the two-buffer activation chunks and the four-slot plane ring with its ONE barrier per tap)
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) == 8, r.stdout + r.stderr
     assert r.returncode == 0 and all(": ok " in l for l in kernels), r.stdout
     for l in kernels:                                        # the emulation really ran the pipeline
         stats = eval(l.split(": ok ", 1)[1])
         assert stats["dma_transfers"] > 400 and stats["lds_reads"] > 3000 and stats["epochs"] >= 30, l
 
 
-@pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0,0", "64,2,1,0,0,0,0,0", "64,4,1,0,0,1,0,0", "128,2,1,0,1,0,1,0"])
+@pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0,0", "64,2,1,0,0,0,0,0", "64,4,1,0,0,1,0,0", "128,2,1,0,1,0,1,0",
+                                    "layer:8,1,0"])
 def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     """Negative controls of the emulation: loosening a steady-state ``vmcnt`` wait by one, removing a tile
     barrier and loosening a fragment ``lgkmcnt`` wait by one must each be reported (pair ring, plain ring,
-    group ring and a split-precision kernel)."""
+    group ring, a split-precision kernel and the layer-wise convolution)."""
     chk = _race_checker()
-    seg = dict(chk.kernels_of(device_asm))[kernel]
+    family = "k_layer_conv" if kernel.startswith("layer:") else "k_trunk_x16"
+    kernel = kernel.split(":")[-1]
+    seg = {(f, t): sg for f, t, sg in chk.kernels_of(device_asm)}[(family, kernel)]
+    kernarg = chk.layer_kernarg(int(kernel.split(",")[1]), False) if family == "k_layer_conv" else None
 
     def run(lines):
         ins, labels = chk.parse_kernel(lines)
         try:
-            return chk.check_workgroup(ins, labels, 1)[0]
+            return chk.check_workgroup(ins, labels, 1, kernarg=kernarg)[0]
         except chk.EmuError as e:
             return ["stopped: %s" % e]
 

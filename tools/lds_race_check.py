@@ -117,7 +117,7 @@ def parse_kernel(lines):
 
 
 class Wave(object):
-    def __init__(self, ins, labels, wave, n_blocks, wg=0, want_out=False, want_heads=True, listed=None):
+    def __init__(self, ins, labels, wave, n_blocks, wg=0, want_out=False, want_heads=True, listed=None, kernarg=None):
         self.ins, self.labels, self.wave = ins, labels, wave
         self.s = [None] * 128                     # None = unknown
         self.v = np.zeros((1024, 64), dtype=U32)  # v0..v511, a0..a511
@@ -137,6 +137,9 @@ class Wave(object):
             self.args[0x18] = LIST_BASE
         if not want_heads:
             self.args[0x38] = 0
+        self.int_args = {0x20: n_blocks}          # k_trunk_x16: int n_blocks behind the four pointers
+        if kernarg is not None:                   # another kernel family: its own pointer arguments, no integer ones
+            self.args, self.int_args = dict(kernarg), {}
         self.n_blocks = n_blocks
         self.events = []                          # (kind, epoch, ...)
         self.epoch = 0
@@ -316,6 +319,8 @@ class Wave(object):
                 self.salu(op, t, mods, text)
             elif op.startswith("ds_"):
                 self.ds(op, t, mods, in_asm, text)
+            elif op.startswith("scratch_"):
+                self.scratch(op, t, mods, text)
             elif op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_"):
                 self.vmem(op, t, mods, text)
             elif op.startswith("v_"):
@@ -351,6 +356,12 @@ class Wave(object):
                     self.scc = (int(full > MASK32) if op in ("s_add_u32", "s_addc_u32")
                                 else int(not -(1 << 31) <= s32(a) + s32(b) < (1 << 31)))
                 self.sset(t[0], full & MASK32)
+        elif op in ("s_bitset1_b32", "s_bitset0_b32"):
+            a, b = g(t[0]), g(t[1])
+            if a is None or b is None:
+                self.sset(t[0], None)
+            else:
+                self.sset(t[0], (a | (1 << (b & 31))) if op == "s_bitset1_b32" else (a & ~(1 << (b & 31)) & MASK32))
         elif op in ("s_mul_i32", "s_mul_hi_u32", "s_mul_hi_i32"):
             a, b = g(t[1]), g(t[2])
             if a is None or b is None:
@@ -447,11 +458,12 @@ class Wave(object):
                 val = None
                 if self.listed is not None and base is not None and LIST_BASE <= base + off + 4 * i < LIST_BASE + 4096:
                     word = (base + off + 4 * i - LIST_BASE) // 4
-                    val = self.listed if word == 0 else (0 if word == 1 else (7 * (word - 2) + 3) & MASK32)
+                    # [0] listed boards, [1..3] statistics words, [LIST_HEADER = 4 ...] the boards
+                    val = self.listed if word == 0 else (0 if word < 4 else (7 * (word - 4) + 3) & MASK32)
                 elif base == KERNARG_BASE:
                     o = off + 4 * i
-                    if o == 0x20:
-                        val = self.n_blocks
+                    if o in self.int_args:
+                        val = self.int_args[o]
                     elif (o & ~7) in self.args:
                         val = (self.args[o & ~7] >> (32 * ((o >> 2) & 1))) & MASK32
                 self.s[idx + i] = val
@@ -496,6 +508,24 @@ class Wave(object):
             self.lgkm.append((frozenset(), text))
         else:
             raise EmuError("LDS opcode " + op)
+
+    # ---- register spills: private memory per lane, by byte offset ("scratch_store_dwordxN off, v[..], off offset:K") ----
+    def scratch(self, op, t, mods, text):
+        n = {"dword": 1, "dwordx2": 2, "dwordx3": 3, "dwordx4": 4}.get(op.split("_")[-1])
+        if n is None or "off" not in t:
+            raise EmuError("scratch opcode " + text)
+        mem = self.__dict__.setdefault("_scratch", {})
+        off = int(mods.get("offset", "0"), 0)
+        if op.startswith("scratch_store"):
+            r = _vreg([x for x in t if _vreg(x) is not None][0])
+            self.touch_read(r[0], r[1])
+            for i in range(n):
+                mem[off + 4 * i] = (self.v[r[0] + i].copy(), self.vk[r[0] + i].copy())
+        else:
+            for i in range(n):
+                vals, known = mem.get(off + 4 * i, (np.zeros(64, U32), self._none))
+                self.vdst(t[0], vals, known, comp=i)
+        self.vm.append(None)
 
     # ---- vector memory --------------------------------------------------------------------------------
     def vmem(self, op, t, mods, text):
@@ -553,7 +583,7 @@ class Wave(object):
             x, k = self.vsrc64(t[1]) if (_vreg(t[1]) or _sreg(t[1])) else (np.full(64, _imm(t[1]) & 0xFFFFFFFFFFFFFFFF, u64), self._all)
             self.vdst64(t[0], x, k)
         elif base in ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mul_lo_u32",
-                      "v_mul_u32_u24", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_min_u32", "v_max_u32",
+                      "v_mul_u32_u24", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32",
                       "v_mul_lo_u16", "v_sub_u16", "v_add_u16", "v_lshrrev_b16", "v_lshlrev_b16", "v_mul_hi_u32"):
             a, ka = src(1, "src0_sel")
             b, kb = src(2, "src1_sel")
@@ -587,6 +617,10 @@ class Wave(object):
                 r = np.minimum(a, b)
             elif base == "v_max_u32":
                 r = np.maximum(a, b)
+            elif base == "v_min_i32":
+                r = np.minimum(a.astype(np.int32), b.astype(np.int32)).astype(U32)
+            elif base == "v_max_i32":
+                r = np.maximum(a.astype(np.int32), b.astype(np.int32)).astype(U32)
             elif base == "v_mul_lo_u16":
                 r = (a * b) & U32(0xFFFF)
             elif base == "v_sub_u16":
@@ -719,6 +753,15 @@ class Wave(object):
             x, k = src(1)
             ln = self.sget(t[2])
             self.sset(t[0], int(x[ln & 63]) if ln is not None and k[ln & 63] else None)
+        elif base == "v_writelane_b32":
+            # vD[lane] = sS (SGPR spills): ignores EXEC
+            r = _vreg(t[0])
+            val, ln = self.sget(t[1]), self.sget(t[2])
+            if ln is None:
+                raise EmuError("v_writelane with an unknown lane: " + text)
+            self.touch_write(r[0], 1)
+            self.v[r[0]][ln & 63] = (val or 0) & MASK32
+            self.vk[r[0]][ln & 63] = val is not None
         elif base == "v_bfrev_b32":
             x, k = src(1)
             r = np.array([int("{:032b}".format(int(v))[::-1], 2) for v in x], dtype=U32)
@@ -740,9 +783,9 @@ class Wave(object):
             self.vunknown(t[0])
 
 
-def check_workgroup(ins, labels, n_blocks, lds_bytes=160 * 1024, want_out=False, listed=None):
+def check_workgroup(ins, labels, n_blocks, lds_bytes=160 * 1024, want_out=False, listed=None, kernarg=None):
     """Emulate the 8 waves of workgroup 0 and cross-check their LDS traffic epoch by epoch."""
-    waves = [Wave(ins, labels, w, n_blocks, want_out=want_out, listed=listed).run() for w in range(8)]
+    waves = [Wave(ins, labels, w, n_blocks, want_out=want_out, listed=listed, kernarg=kernarg).run() for w in range(8)]
     findings = []
     for w in waves:
         for kind, line, msg in w.findings:
@@ -808,33 +851,51 @@ def check_workgroup(ins, labels, n_blocks, lds_bytes=160 * 1024, want_out=False,
 
 
 def kernels_of(path):
+    """[(family, template arguments, instruction lines)] of every kernel with hand-counted pipelines: the fused trunk
+    k_trunk_x16<...> (tower_x16.hpp) and the layer-wise convolution k_layer_conv<CHUNKS, KIND, IDX> (tower_layer.hpp)."""
     L = open(path).read().split("\n")
-    starts = [(i, l.split(":")[0]) for i, l in enumerate(L) if l.startswith("_ZN9crl_tower11k_trunk_x16")]
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(L) if re.match(r"_ZN9crl_tower\d+k_(trunk_x16|layer_conv)I", l)]
     out = []
     for i, name in starts:
         end = next(j for j in range(i, len(L)) if "s_endpgm" in L[j])
-        tmpl = re.search(r"k_trunk_x16I(.*?)EEv", name).group(1).replace("Li", "").replace("E", ",").rstrip(",")
-        out.append((tmpl, L[i + 1:end + 1]))
+        m = re.search(r"\d+(k_trunk_x16|k_layer_conv)I(.*?)EEv", name)
+        tmpl = m.group(2).replace("Li", "").replace("E", ",").rstrip(",")
+        out.append((m.group(1), tmpl, L[i + 1:end + 1]))
     return out
 
 
+# k_layer_conv(act_in, wts, bias, act_out, list, head_w, head_b, head_out, out): pointers only
+def layer_kernarg(kind, indexed):
+    return {0x00: 0x10000000, 0x08: 0x20000000, 0x10: 0x30000000, 0x18: 0x40000000, 0x20: LIST_BASE if indexed else 0,
+            0x28: 0x50000000, 0x30: 0x60000000, 0x38: 0x70000000 if kind == 3 else 0, 0x40: 0}
+
+
 def check_kernel(args):
-    tmpl, seg, n_blocks = args
+    family, tmpl, seg, n_blocks = args
     ins, labels = parse_kernel(seg)
-    # an indexed kernel (8th template argument) takes its boards from a list: one listed board, so that a
-    # workgroup of several boards runs with its padding (the last entry repeated)
-    indexed = len(tmpl.split(",")) > 7 and tmpl.split(",")[7] == "1"
+    targs = tmpl.split(",")
     try:
-        findings, stats = check_workgroup(ins, labels, n_blocks, listed=1 if indexed else None)
+        if family == "k_layer_conv":
+            # one launch = one convolution (the whole kernel is executed: 4 or 8 K-chunks x 9 taps); an indexed launch
+            # with one listed board runs with its padding
+            indexed = targs[2] == "1"
+            findings, stats = check_workgroup(ins, labels, 0, listed=1 if indexed else None,
+                                              kernarg=layer_kernarg(int(targs[1]), indexed))
+        else:
+            # an indexed kernel (8th template argument) takes its boards from a list: one listed board, so that a
+            # workgroup of several boards runs with its padding (the last entry repeated)
+            indexed = len(targs) > 7 and targs[7] == "1"
+            findings, stats = check_workgroup(ins, labels, n_blocks, listed=1 if indexed else None)
     except EmuError as e:
         findings, stats = ["emulation stopped: %s" % e], {}
-    return tmpl, findings, stats
+    return family, tmpl, findings, stats
 
 
 def main(path, n_blocks=2, only=None, jobs=None):
     import multiprocessing
     import os
-    work = [(tmpl, seg, n_blocks) for tmpl, seg in kernels_of(path) if only is None or only in tmpl]
+    work = [(family, tmpl, seg, n_blocks) for family, tmpl, seg in kernels_of(path)
+            if only is None or only in tmpl or only in family]
     jobs = jobs or min(len(work), os.cpu_count() or 1)
     if jobs > 1:
         with multiprocessing.Pool(jobs) as pool:
@@ -842,9 +903,9 @@ def main(path, n_blocks=2, only=None, jobs=None):
     else:
         results = [check_kernel(w) for w in work]
     total = 0
-    for tmpl, findings, stats in results:
-        print("k_trunk_x16<%s> (%d residual blocks): %s  %s" % (tmpl, n_blocks, "ok" if not findings else
-                                                                "%d findings" % len(findings), stats))
+    for family, tmpl, findings, stats in results:
+        what = "%d residual blocks" % n_blocks if family == "k_trunk_x16" else "one convolution"
+        print("%s<%s> (%s): %s  %s" % (family, tmpl, what, "ok" if not findings else "%d findings" % len(findings), stats))
         for f in findings[:12]:
             print("      " + f)
         total += len(findings)

@@ -5,7 +5,7 @@
 # domain); the program after -- is python3 itself.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 O=$R/gpurun_out/prof_$ROUND
 mkdir -p $O
 pmc() {   # name counter cmd...
@@ -24,11 +24,27 @@ pmc trunk128x3 FETCH_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
 pmc trunk128x3 WRITE_SIZE python3 $R/tools/trunk_once.py 10 128 4096 f16x3
 pmc trunk256x3 FETCH_SIZE python3 $R/tools/trunk_once.py 20 256 4096 f16x3
 pmc trunk256x3 WRITE_SIZE python3 $R/tools/trunk_once.py 20 256 4096 f16x3
+# SQ pass (one run, four SQ counters -- the block has 8 slots -- + GRBM_GUI_ACTIVE for the clock) over the three C3 kernels auto / hybrid dispatch and the layer-wise
+# kernels of C5's compliant mode: MFMA busy cycles, wave cycles, LDS instructions, LDS bank conflicts
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
+sq() {   # name cmd...
+  local name=$1; shift
+  rm -rf /tmp/sq_$name
+  timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/sq_$name -- "$@" > /dev/null 2>&1
+  find /tmp/sq_$name -name "*counter_collection.csv" -exec cp {} $O/${name}_SQ.csv \;
+}
+sq trunk128 python3 $R/tools/trunk_once.py 10 128 4096
+sq trunk128x3 python3 $R/tools/trunk_once.py 10 128 4096 f16x3
+sq trunk128idx python3 $R/tools/trunk_once.py 10 128 4096 indexed
+sq trunk256x3 python3 $R/tools/trunk_once.py 20 256 4096 f16x3
+sq trunk256 python3 $R/tools/trunk_once.py 20 256 4096
 pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 1
 pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
 pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0
 pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
-for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
+# (c5: --no-graph -- rocprofv3's kernel tracing of ROCm 7.2 segfaults inside hipGraphLaunch when a graph holds the ~1000 kernel
+# nodes of eight C5 hybrid steps (42 launches per layer-wise tower forward); eager launches run the same kernels)
+for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20 --no-graph" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
