@@ -491,7 +491,8 @@ class ChessModel(object):
         caller records ``end`` behind its launch.  None (the default) costs one attribute test."""
         if self.trunk_events is None:
             return None
-        ev = (kind, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        make = getattr(self, "trunk_event_cls", None) or torch.cuda.Event      # (bench.py: events without a system fence)
+        ev = (kind, make(enable_timing=True), make(enable_timing=True))
         ev[1].record()
         self.trunk_events.append(ev)
         return ev

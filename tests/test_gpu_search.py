@@ -472,6 +472,38 @@ def test_fused_trunk_from_bitplanes_is_bit_identical(filters, n_boards):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_boards", [30, 516])
+def test_layerwise_split_trunk_of_256_filters_both_plane_formats_trunk_output_and_batch_independence(n_boards):
+    """csrc/tower_layer.hpp (256 filters, CRL_TRUNK_SPLIT: one launch per convolution, activations through the
+    caller's workspace): the same bits from fp16 planes and from plane bitboards; the trunk's fp32 output and the head
+    activations against the fp32 PyTorch tower at fp32-grade accuracy; and ONE arithmetic whatever the batch -- a
+    board evaluated in a batch of 4 carries the bits it has in the big batch (the hybrid mode's indexed launches and
+    a thinning lockstep batch rely on it)."""
+    from chessrl_amd.model import ChessModel
+    w = tower_oracle.init_weights(3, 256, seed=12, randomize_bn=True)
+    model = ChessModel(weights=w, precision="f16x3")
+    ref = ChessModel(weights=w, dtype=torch.float32, fused=False)
+    rng = np.random.default_rng(256 + n_boards)
+    planes = torch.zeros((n_boards, 8, 8, 128), dtype=torch.float16, device="cuda:0")
+    planes[..., :127] = torch.from_numpy((rng.random((n_boards, 8, 8, 127)) < 0.2).astype(np.float16)).cuda()
+    bits = _bits_from_planes(planes)
+    t0, h0 = model._run_fused(planes, want_trunk=True)
+    t1, h1 = model._run_fused(bits, want_trunk=True)
+    assert torch.equal(t0, t1) and torch.equal(h0, h1)
+    with torch.no_grad():
+        exp = ref.net.trunk(planes.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    scale = exp.abs().max().item()
+    assert (t0 - exp).abs().max().item() <= 2e-5 * scale                # three MFMAs per product: fp32-grade
+    _, h_none = model._run_fused(bits)                                  # without the trunk output: same head rows
+    assert torch.equal(h_none, h0)
+    for first in (0, 4 * ((n_boards - 4) // 4)):
+        _, hs = model._run_fused(bits[first:first + 4].contiguous())
+        assert torch.equal(hs, h0[first:first + 4])
+    (p0, v0), (p1, v1) = model(planes), model(bits)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sliced", [False, True])
 @pytest.mark.parametrize("n_boards", [5, 64, 1000])
 def test_legal_priors_head_writes_the_full_policy_at_the_listed_labels(n_boards, sliced):
