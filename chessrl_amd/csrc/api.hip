@@ -673,7 +673,8 @@ static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, co
     const conv_t stem = list ? (conv_t)crl_tower::k_layer_conv<4, 0, 1> : (conv_t)crl_tower::k_layer_conv<4, 0, 0>;
     const conv_t c1 = list ? (conv_t)crl_tower::k_layer_conv<8, 1, 1> : (conv_t)crl_tower::k_layer_conv<8, 1, 0>;
     const conv_t c2 = list ? (conv_t)crl_tower::k_layer_conv<8, 2, 1> : (conv_t)crl_tower::k_layer_conv<8, 2, 0>;
-    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1> : (conv_t)crl_tower::k_layer_conv<8, 3, 0>;
+    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1>
+                           : (out_f32 ? (conv_t)crl_tower::k_layer_conv<8, 4, 0> : (conv_t)crl_tower::k_layer_conv<8, 3, 0>);
     for (conv_t k : { stem, c1, c2, c3 }) {
         hipError_t ea = allow_big_lds((const void *)k, G::LDS_BYTES);
         if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__res
 //            rewritten IN PLACE (a lane reads exactly the bytes it then writes)
 // KIND 0: linear (the stem, model.py:33-34: no BN, no activation); 1: ReLU (first convolution of a block); 2: + X, ReLU
 // (second); 3: as 2, and the tail of the tower: the three 1x1 head convolutions reduced to head_out f32 [n][192] (as
-// k_trunk_x16 leaves them) and, if out != nullptr, the trunk's output f32 [n][64][256].
+// k_trunk_x16 leaves them); 4: as 3, and the trunk's output to out f32 [n][64][256] (tests; its own instance so that the
+// product's last layer carries neither the branch nor the registers).
 // IDX: the launch covers the list's boards (k_layer_expand); a workgroup beyond it leaves at once; head_out rows by the list.
 template <int CHUNKS, int KIND, int IDX>
 __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__restrict__ act_in,
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     // ---- epilogue: a lane holds, per (pt, g), the 8 consecutive channels obase + 32 g + 8 q .. + 7 of position 16 pt + r
     unsigned char *outp = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
     float part[PT][3];                                  // KIND 3: partial sums of the three head convolutions
-    if constexpr (KIND == 3) {
+    if constexpr (KIND >= 3) {
         // (opaque from here on: the head weights are loop invariants of the epilogue; hipcc would otherwise load all 96 of
         // a lane's values in front of the tap loop and spill accumulators to keep them)
         asm volatile("" : "+s"(head_w), "+s"(out));
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
 #pragma unroll
                     for (int j = 0; j < 4; j++) o[h][j] = fmaxf(o[h][j], 0.f);
             }
-            if constexpr (KIND == 3) {
+            if constexpr (KIND >= 3) {
                 const int o0 = obase + 32 * g + 8 * q;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
 #pragma unroll
                     for (int j = 0; j < 4; j++) part[pt][k] += o[1][j] * wb[j];
                 }
-                if (!IDX && out) {
+                if constexpr (KIND == 4) {
                     float *op = out + (((size_t)blockIdx.x * 4 + board) * 64 + 16 * pt + r) * G::F + o0;
                     *reinterpret_cast<f32x4 *>(op) = f32x4{o[0][0], o[0][1], o[0][2], o[0][3]};
                     *reinterpret_cast<f32x4 *>(op + 4) = f32x4{o[1][0], o[1][1], o[1][2], o[1][3]};
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
                 *reinterpret_cast<half8 *>(dst + 64) = lo8;
             }
         }
-    if constexpr (KIND == 3) {
+    if constexpr (KIND >= 3) {
         // a position's 256 channels live in 2 waves x 4 lane quarters x ... : 8 partial sums per output, added in a fixed
         // order (no float atomics: results are reproducible); the LDS is free (every wave is past its last fragment read
         // once it is past the barrier below)

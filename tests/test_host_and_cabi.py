@@ -407,7 +407,7 @@ def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(device_a
                        capture_output=True, text=True)
     kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
     # every dispatched k_trunk_x16<F, NB, BITS, PAIR, GROUP, SPLIT, IDX> + the layer-wise k_layer_conv<CHUNKS, KIND, IDX>
-    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) == 8, r.stdout
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 9, r.stdout
     assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
 
 
@@ -437,7 +437,7 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
     kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
     # (round 5: also the layer-wise convolution kernels of csrc/tower_layer.hpp, one whole convolution each: 72 taps,
     # the two-buffer activation chunks and the four-slot plane ring with its ONE barrier per tap)
-    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) == 8, r.stdout + r.stderr
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 9, r.stdout + r.stderr
     assert r.returncode == 0 and all(": ok " in l for l in kernels), r.stdout
     for l in kernels:                                        # the emulation really ran the pipeline
         stats = eval(l.split(": ok ", 1)[1])

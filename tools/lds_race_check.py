@@ -867,7 +867,7 @@ def kernels_of(path):
 # k_layer_conv(act_in, wts, bias, act_out, list, head_w, head_b, head_out, out): pointers only
 def layer_kernarg(kind, indexed):
     return {0x00: 0x10000000, 0x08: 0x20000000, 0x10: 0x30000000, 0x18: 0x40000000, 0x20: LIST_BASE if indexed else 0,
-            0x28: 0x50000000, 0x30: 0x60000000, 0x38: 0x70000000 if kind == 3 else 0, 0x40: 0}
+            0x28: 0x50000000, 0x30: 0x60000000, 0x38: 0x70000000 if kind >= 3 else 0, 0x40: 0x78000000 if kind == 4 else 0}
 
 
 def check_kernel(args):

@@ -1,6 +1,6 @@
 """Scratch (GPU): self-play games per hour over whole games, stop-and-train rounds against rolling rounds
 (SelfPlayRunner.run_rolling) at C3: G games in lockstep, S sims/move, 10x128 random-init tower.
-python tools/rolling_probe.py [G=4096] [S=800] [rounds=3] [round_size=G] [train]
+python tools/rolling_probe.py [G=4096] [S=800] [rounds=3] [round_size=G] [train | notrain] [share=0.2] [tower=10x128]
 Reports when each round was handed over and, from the timeline of finished games, the rate over every
 window of `round_size` consecutively finished games (the accounting window).  With `train` every round is
 handed to the background trainer (chessrl_amd.selfplay.BackgroundTrainer: rank 0's thread and stream) as the
@@ -22,7 +22,11 @@ R = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N = int(sys.argv[4]) if len(sys.argv) > 4 else G
 TRAIN = len(sys.argv) > 5 and sys.argv[5] == "train"
 SHARE = float(sys.argv[6]) if len(sys.argv) > 6 else 0.2      # of the wall time, to the trainer while it has work
-model = ChessModel(blocks=10, filters=128, precision="f16" if not TRAIN else "auto")
+TOWER = [int(x) for x in (sys.argv[7] if len(sys.argv) > 7 else "10x128").split("x")]
+# precision "auto" (what the product runs): the probe decides, and the run-time guard of an auto-kept f16 re-checks it on the
+# run's own tree leaves every 8 move boundaries (rounds 3-4 ran the no-training probe in --precision f16)
+model = ChessModel(blocks=TOWER[0], filters=TOWER[1], precision="auto")
+START_PRECISION = model.precision
 run = SelfPlayRunner(model, G, S, seed=0, noise=True, total_games=R * N, round_size=N, max_plies=4096)
 t0 = time.time()
 timeline = []                                   # (seconds, games finished so far, slots in the batch)
@@ -79,7 +83,8 @@ for k in range(0, int(tl[-1, 1]) - N + 1, max(1, N // 4)):
     ta = tl[np.searchsorted(tl[:, 1], k, side="left"), 0] if k > 0 else 0.0
     tb = tl[np.searchsorted(tl[:, 1], k + N, side="left"), 0]
     windows.append({"from_game": k, "seconds": float(tb - ta), "games_per_hour": N / (tb - ta) * 3600.0})
-out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "10x128 %s" % model.precision, "round_size": N, "rounds": rounds,
+out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "%dx%d %s" % (TOWER[0], TOWER[1], model.precision),
+       "tower_precision_at_start": START_PRECISION, "tower_precision_guard": model.guard, "round_size": N, "rounds": rounds,
        "training_in_the_loop": TRAIN, "trainer_share": SHARE if TRAIN else None, "weight_loads": loads, "trainer": trainer if TRAIN else None,
        "seconds_until_last_round_trained": (time.time() - t0) if TRAIN else None,
        "rounds_done": done, "seconds_total": total, "games_total": int(tl[-1, 1]), "sims_run": run.sims_run,
