@@ -28,8 +28,8 @@
 // ~600-us layer, and it is the coherence point between a layer's stores and the next layer's loads; a persistent launch
 // would have to hand-roll that and gains nothing (each workgroup's next layer depends on its own stores having landed).
 // Measured (tools/ubench/conv_layer.hip, 4096 boards, one 256 -> 256 convolution incl. activation read + write): the loop
-// alone 0.526 ms = 0.705 of the MFMA peak in issued FLOPs; first / second convolution of a block 0.57 / 0.62 ms
-// (k_trunk_x16<256, 1, SPLIT>: 0.82 ms per convolution).
+// alone 0.526 ms = 0.705 of the MFMA peak in issued FLOPs; first / second convolution of a block 0.563 / 0.606 ms = rocprofv3's
+// 562.9 / 608.4 us inside a C5 bench (profiles/r05); k_trunk_x16<256, 1, SPLIT> took 0.82 ms per convolution.
 // Accumulation order per output: chunk-major, tap, (hi.Whi, lo.Whi, hi.Wlo) -- NOT the order of k_trunk_x16 (tap-major): the
 // library runs ONE arithmetic per (filters, mode), so at 256 filters every split-precision evaluation -- any batch size, the
 // indexed fall-back launch of the hybrid mode too -- goes through these kernels.
