@@ -3,7 +3,7 @@ process keeps the GPU busy (its workgroups share CUs and LDS bandwidth with ours
 jitter)?  A kernel that touches a register before its hand-counted wait has made it valid passes every
 single-process test and fails here (round 3: the 64-filter split-precision kernels, 45-90 % of the
 launches wrong; cause and static check: tools/check_asm_hazards.py).
-    python tools/trunk_stability_probe.py disturb 400 &  python tools/trunk_stability_probe.py measure 150
+    python tools/trunk_stability_probe.py disturb 400 &  python tools/trunk_stability_probe.py measure 150 [BxFxN,...]
 A second disturber, ``stream N``, delays the OTHER side of the pipeline: it streams two 4-GiB buffers through
 the L2s and HBM (copies, N times), so that the weight tiles' LDS-DMA (L2 -> LDS) arrives late and a ring slot
 read before its counted ``vmcnt`` wait + barrier shows (static counterpart: tools/lds_race_check.py)."""
@@ -31,7 +31,10 @@ elif role == "stream":                    # a bandwidth hog: 8 GiB of traffic pe
     print("streamer done", flush=True)
 else:
     reps = int(sys.argv[2])
-    for blocks, filters, n in ((1, 64, 256), (1, 64, 2048), (2, 128, 256), (2, 128, 2048), (1, 256, 256), (1, 256, 1024)):
+    shapes = ((1, 64, 256), (1, 64, 2048), (2, 128, 256), (2, 128, 2048), (1, 256, 256), (1, 256, 1024))
+    if len(sys.argv) > 3:                 # e.g. 4x256x4096: the layer-wise kernels over full rounds of workgroups
+        shapes = tuple(tuple(int(x) for x in sh.split("x")) for sh in sys.argv[3].split(","))
+    for blocks, filters, n in shapes:
         m = ChessModel(blocks=blocks, filters=filters, seed=5, precision="f16")
         planes = M._probe_bitplanes(m.device, 256).repeat(n // 256, 1).contiguous()
         m.precision_requested = "auto"; m._pack_fused(m.weights)
