@@ -36,6 +36,15 @@
 #pragma once
 #include "tower_x16.hpp"
 
+// 1: inside the tap loop only waves 0 - 3 request the LDS-DMA transfers (twice the pieces each); their SIMD partners 4 - 7 go
+// straight on with their MFMAs (see the tap body).  0: every wave requests its share behind the barrier.
+#ifndef CRL_LAYER_DMA_HALF
+#define CRL_LAYER_DMA_HALF 0
+#endif
+#ifndef CRL_LAYER_ASM_MFMA
+#define CRL_LAYER_ASM_MFMA 0
+#endif
+
 namespace crl_tower {
 
 struct LayerGeo {
@@ -248,6 +257,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+#if defined(CRL_LAYER_STAMPS)
+    // harness diagnostic (tools/ubench/conv_layer.hip -DCRL_LAYER_STAMPS): cycles a wave spends waiting for its DMA, at the
+    // tap barrier, requesting DMA, in the whole loop and in the epilogue; written to `out` (never in the product)
+    unsigned long long st_vm = 0, st_sb = 0, st_dma = 0, st_loop = 0, st_epi = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#endif
     half8 x[2][PT], w[2][HC];
     int ab[PT], abn[PT];
 
@@ -269,8 +283,19 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
 #pragma unroll
         for (int pt = 0; pt < PT; pt++)
 #pragma unroll
-            for (int c = 0; c < HC; c++)
+            for (int c = 0; c < HC; c++) {
+#if CRL_LAYER_ASM_MFMA
+                // accumulator tied in place ("+v"): hipcc otherwise gives some MFMAs another destination than their C
+                // operand, moves accumulators around (100+ v_mov per chunk) and, as soon as the tap body holds a branch or a
+                // second DMA site, spills dozens of them inside the loop.  Every hazard of these MFMAs is then ours: their
+                // operands come from asm ds_reads behind counted waits; the first reader of the results is the epilogue,
+                // behind the s_nops that follow the loop.
+                f32x4v &a = acc[pt][half * HC + c];
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a) : "v"(ww[c]), "v"(xx[pt]));
+#else
                 acc[pt][half * HC + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ww[c], xx[pt], acc[pt][half * HC + c], 0, 0, 0);
+#endif
+            }
     };
 
     // cold start: hi rows of (chunk 0, tap 0) and Whi[0:4]
@@ -336,9 +361,51 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         __builtin_amdgcn_sched_barrier(0);
         // barrier: every fragment read of this tap's two planes has landed (only the next tap's x may be in flight)
         wait_lgkm_n<PT>();
+#if defined(CRL_LAYER_STAMPS)
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+        wait_vmcnt_n<0>();
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+        st_vm += s1 - s0;
+        st_sb += s2 - s1;
+#else
         wait_vmcnt_n<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#endif
+#if CRL_LAYER_DMA_HALF
+        // The two waves of a SIMD (w and w + 4) leave the barrier together, and a request costs its wave ~115 cycles in which
+        // it issues no MFMA (in-kernel stamps: 540 cycles per tap and wave, 11 % of the loop, both partners at the same
+        // time).  Only waves 0 - 3 request -- all 32 plane pieces of the tap after next and, in the first five taps of a
+        // chunk, two pieces each of the next chunk: their partners compute meanwhile and wait for them at the next barrier,
+        // where the roles are reversed.
+        if (wave_u < 4) {
+            const int un = u + 2 < CHUNKS * G::TAPS ? u + 2 : CHUNKS * G::TAPS - 1;
+            const unsigned char *src = uniform_ptr(wts + (size_t)(2 * un) * G::TILE);
+#pragma unroll
+            for (int j = 0; j < 8; j++)                 // two planes = 32 KiB contiguous in the stream: pieces 4 j + wave
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + (unsigned)(j * 4096) + woff[0]),
+                    (__attribute__((address_space(3))) void *)(lds + G::WRING_OFF + (2 * P + (j >> 2)) * G::TILE + (j & 3) * 4096 + wave_u * 1024),
+                    16, 0, 0);
+            if constexpr (t < 5) {
+                const int cn = c + 1 < CHUNKS ? c + 1 : CHUNKS - 1;
+                const unsigned char *asrc = uniform_ptr(act + (size_t)cn * G::CHUNK_BYTES);
+#pragma unroll
+                for (int jj = 2 * t; jj < 2 * t + 2; jj++) {   // this wave: rows 64 w .. 64 w + 63 = 10 pieces of the padded image
+                    int g = jj * 64 + lane;
+                    asm volatile("" : "+v"(g));
+                    const int rl = (g * 0xCCCD) >> 19, col = g - rl * 10;
+                    const unsigned vo = (unsigned)((wave * 64 + rl) * G::GROW + (col < 8 ? col : 0) * 16);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(asrc + vo),
+                        (__attribute__((address_space(3))) void *)(lds + ((c + 1) & 1) * G::ACHUNK + wave_u * 10240 + jj * 1024), 16, 0, 0);
+                }
+            }
+        }
+#else
         {
             const int un = u + 2 < CHUNKS * G::TAPS ? u + 2 : CHUNKS * G::TAPS - 1;
             layer_stage_w(wts, lds, 2 * un, 2 * P, woff, wave_u);
@@ -349,6 +416,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
             const int cn = c + 1 < CHUNKS ? c + 1 : CHUNKS - 1;
             layer_stage_act(act, lds, cn, (c + 1) & 1, t, voff[t < 5 ? t : 0], wave_u);
         }
+#endif
+#if defined(CRL_LAYER_STAMPS)
+        st_dma += __builtin_amdgcn_s_memtime() - s2;
+#endif
         // S6
         rd_w(w[1 - P], SNEXT{}, I0{});
         __builtin_amdgcn_sched_barrier(0);
@@ -372,6 +443,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         wait_lgkm_n<0>();
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if CRL_LAYER_ASM_MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results are read below (16 passes of 4 cycles)
+#endif
+#if defined(CRL_LAYER_STAMPS)
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();
+    st_loop = st_t1 - st_t0;
+#endif
 
     // ---- epilogue: a lane holds, per (pt, g), the 8 consecutive channels obase + 32 g + 8 q .. + 7 of position 16 pt + r
     unsigned char *outp = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
@@ -465,6 +543,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
             head_out[gb * 192 + (k < 2 ? pos * 2 + k : 128 + pos)] = fmaxf(v, 0.f);
         }
     }
+#if defined(CRL_LAYER_STAMPS)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_epi = __builtin_amdgcn_s_memtime() - st_t1;
+    if (lane == 0 && out) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(out) + ((size_t)blockIdx.x * 8 + wave) * 5;
+        dbg[0] = st_loop; dbg[1] = st_epi; dbg[2] = st_vm; dbg[3] = st_sb; dbg[4] = st_dma;
+    }
+#endif
 }
 
 }  // namespace crl_tower

@@ -132,5 +132,27 @@ int main(int argc, char **argv)
         printf("    check: 3000 sampled outputs vs CPU: max |err| %.3g (hi + lo), %d beyond 2e-5 relative -> %s\n", worst, bad, bad ? "WRONG" : "ok");
         fflush(stdout);
     }
+#if defined(CRL_LAYER_STAMPS)
+    {   // in-kernel cycle stamps (hipcc ... -DCRL_LAYER_STAMPS): per wave [loop, epilogue, vmcnt wait, barrier, DMA requests]
+        unsigned long long *d_dbg; const size_t n_dbg = (size_t)n_wg * 8 * 5;
+        CK(hipMalloc(&d_dbg, n_dbg * 8));
+        for (int mode = 1; mode <= 2; mode++) {
+            kern_t k = mode == 1 ? (kern_t)k_layer_conv<8, 1, 0> : (kern_t)k_layer_conv<8, 2, 0>;
+            CK(hipMemset(d_dbg, 0, n_dbg * 8));
+            for (int i = 0; i < 3; i++)
+                hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, (float *)d_dbg);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> dbg(n_dbg);
+            CK(hipMemcpy(dbg.data(), d_dbg, n_dbg * 8, hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0};
+            for (size_t i = 0; i < n_dbg; i++) sum[i % 5] += (double)dbg[i];
+            const double nw = (double)n_wg * 8;
+            printf("stamps KIND %d, mean cycles per wave: loop %.0f (vmcnt wait %.0f = %.1f %%, barrier %.0f = %.1f %%, DMA requests %.0f = %.1f %%; "
+                   "72 taps x 96 MFMAs x 16 = 110592 MFMA-issue cycles = %.1f %% of the loop, x 2 waves per SIMD), epilogue %.0f = %.1f %% of loop + epilogue\n",
+                   mode, sum[0] / nw, sum[2] / nw, 100 * sum[2] / sum[0], sum[3] / nw, 100 * sum[3] / sum[0], sum[4] / nw, 100 * sum[4] / sum[0],
+                   100 * 110592.0 / (sum[0] / nw), sum[1] / nw, 100 * sum[1] / (sum[0] + sum[1]));
+        }
+    }
+#endif
     return 0;
 }
