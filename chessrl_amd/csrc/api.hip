@@ -655,26 +655,25 @@ static bool trunk_is_layerwise(int filters, int flags)
     return filters == 256 && (flags & CRL_TRUNK_SPLIT);
 }
 
-static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
-                               int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
-                               void *workspace, const int32_t *list)
+extern "C++" {
+template <int NB>
+static int layer_trunk_launch(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
+                              int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
+                              void *workspace, const int32_t *list)
 {
-    typedef crl_tower::LayerGeo G;
-    if (!workspace || n_blocks < 1 || !head_out)
-        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the layer-wise 256-filter split-precision trunk needs its "
-                                           "workspace (crl_trunk_workspace_bytes), at least one residual block and head_out");
-    const int n_wg = n_boards / 4;
+    typedef crl_tower::LayerGeoT<NB> G;
+    const int n_wg = n_boards / NB;
     unsigned char *A = (unsigned char *)workspace, *B = A + (size_t)n_wg * G::ACT_WG_BYTES;
     typedef void (*conv_t)(const unsigned char *, const unsigned char *, const float *, unsigned char *, const int *,
                            const float *, const float *, float *, float *);
     typedef void (*expand_t)(const unsigned char *, unsigned char *, const int *);
-    const expand_t ex = list ? (bits ? (expand_t)crl_tower::k_layer_expand<1, 1> : (expand_t)crl_tower::k_layer_expand<0, 1>)
-                             : (bits ? (expand_t)crl_tower::k_layer_expand<1, 0> : (expand_t)crl_tower::k_layer_expand<0, 0>);
-    const conv_t stem = list ? (conv_t)crl_tower::k_layer_conv<4, 0, 1> : (conv_t)crl_tower::k_layer_conv<4, 0, 0>;
-    const conv_t c1 = list ? (conv_t)crl_tower::k_layer_conv<8, 1, 1> : (conv_t)crl_tower::k_layer_conv<8, 1, 0>;
-    const conv_t c2 = list ? (conv_t)crl_tower::k_layer_conv<8, 2, 1> : (conv_t)crl_tower::k_layer_conv<8, 2, 0>;
-    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1>
-                           : (out_f32 ? (conv_t)crl_tower::k_layer_conv<8, 4, 0> : (conv_t)crl_tower::k_layer_conv<8, 3, 0>);
+    const expand_t ex = list ? (bits ? (expand_t)crl_tower::k_layer_expand<1, 1, NB> : (expand_t)crl_tower::k_layer_expand<0, 1, NB>)
+                             : (bits ? (expand_t)crl_tower::k_layer_expand<1, 0, NB> : (expand_t)crl_tower::k_layer_expand<0, 0, NB>);
+    const conv_t stem = list ? (conv_t)crl_tower::k_layer_conv<4, 0, 1, NB> : (conv_t)crl_tower::k_layer_conv<4, 0, 0, NB>;
+    const conv_t c1 = list ? (conv_t)crl_tower::k_layer_conv<8, 1, 1, NB> : (conv_t)crl_tower::k_layer_conv<8, 1, 0, NB>;
+    const conv_t c2 = list ? (conv_t)crl_tower::k_layer_conv<8, 2, 1, NB> : (conv_t)crl_tower::k_layer_conv<8, 2, 0, NB>;
+    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1, NB>
+                           : (out_f32 ? (conv_t)crl_tower::k_layer_conv<8, 4, 0, NB> : (conv_t)crl_tower::k_layer_conv<8, 3, 0, NB>);
     for (conv_t k : { stem, c1, c2, c3 }) {
         hipError_t ea = allow_big_lds((const void *)k, G::LDS_BYTES);
         if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
@@ -700,6 +699,22 @@ static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, co
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
+}
+}  // extern "C++"
+
+static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
+                               int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
+                               void *workspace, const int32_t *list)
+{
+    if (!workspace || n_blocks < 1 || !head_out)
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the layer-wise 256-filter split-precision trunk needs its "
+                                           "workspace (crl_trunk_workspace_bytes), at least one residual block and head_out");
+    // Four boards per workgroup for full batches; two for the indexed launches of the hybrid mode (a list is a few hundred
+    // boards: twice the workgroups on otherwise idle CUs, half the work each) and for batches of at most 512 boards.
+    // Every output is accumulated in the same order in both geometries: the same bits.
+    if (list || n_boards <= 512)
+        return layer_trunk_launch<2>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
+    return layer_trunk_launch<4>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
 }
 
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, int flags,

@@ -47,22 +47,32 @@
 
 namespace crl_tower {
 
-struct LayerGeo {
-    static constexpr int F = 256, NB = 4, ROWS = NB * 64, TAPS = 9;
+// NB boards per workgroup: 4 (full batches: a wave owns one board x 128 channels) or 2 (the hybrid mode's indexed fall-back
+// launches and batches of at most 512 boards: twice the workgroups, a wave owns one board x 64 channels -- 4 x 4 accumulator
+// blocks --, every output accumulated in the same order: the same bits).
+template <int NB_>
+struct LayerGeoT {
+    static_assert(NB_ == 4 || NB_ == 2, "boards per workgroup");
+    static constexpr int F = 256, NB = NB_, ROWS = NB * 64, TAPS = 9;
+    static constexpr int CT = NB == 4 ? 8 : 4;           // 16-channel blocks per wave
+    static constexpr int WPB = 8 / NB;                   // waves per board
     static constexpr int GROW = 128;                     // bytes of a row in the global image: hi 32 | lo 32 halves
     static constexpr int AROW = 160;                     // ... in LDS: + 32 B pad = 10 sixteen-byte units: the 16 lanes of a
                                                          // ds_read_b128 group (8 rows at quarter q, 8 at q + 1) cover all 64 banks
-    static constexpr int ACHUNK = ROWS * AROW;           // 40 KiB
-    static constexpr int ZERO_OFF = 2 * ACHUNK;
+    static constexpr int ACHUNK = ROWS * AROW;           // 40 KiB (20 KiB)
+    static constexpr int APIECES = NB == 4 ? 5 : 3;      // 1-KiB DMA pieces per wave and chunk (NB 2: 24 pieces for 20 KiB,
+    static constexpr int ABUF = APIECES * 8 * 1024;      // the last four land in a tail nobody reads)
+    static constexpr int ZERO_OFF = 2 * ABUF;
     static constexpr int ZERO_BYTES = 16 * AROW;
     static constexpr int WRING_OFF = ((ZERO_OFF + ZERO_BYTES + 1023) / 1024) * 1024;
     static constexpr int TILE = F * 64;                  // one weight plane: [256 rows][64 B]
     static constexpr int LDS_BYTES = WRING_OFF + 4 * TILE;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES <= 160 * 1024 && ABUF >= ACHUNK, "LDS budget");
     static constexpr int CHUNK_BYTES = ROWS * GROW;      // one K-chunk of a workgroup's activations in the global image
-    static constexpr int ACT_WG_BYTES = (F / 32) * CHUNK_BYTES;   // 256 KiB of (hi, lo) activations per workgroup and layer
+    static constexpr int ACT_WG_BYTES = (F / 32) * CHUNK_BYTES;   // 64 KiB of (hi, lo) activations per board and layer
     static constexpr size_t conv_bytes(int chunks) { return (size_t)chunks * TAPS * 2 * TILE; }   // weight planes of one conv
 };
+typedef LayerGeoT<4> LayerGeo;
 
 // uniform 64-bit base in SGPRs + unsigned 32-bit lane offset (through readfirstlane so that hipcc does not fold the lane
 // offset into per-plane 64-bit lane addresses that it then hoists and spills)
@@ -75,25 +85,28 @@ __device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char 
 
 // stage weight plane T of the stream (global image = LDS image, contiguous) into ring slot `slot`: 2 pieces of 1 KiB per
 // wave; woff[j] = the lane's byte offset inside the plane for piece j
+template <class G>
 __device__ __forceinline__ void layer_stage_w(const unsigned char *wts, lds_byte *lds, int T, int slot, const unsigned (&woff)[2], int wave_u)
 {
-    const unsigned char *src = uniform_ptr(wts + (size_t)T * LayerGeo::TILE);
-    const int dst0 = LayerGeo::WRING_OFF + slot * LayerGeo::TILE + wave_u * 1024;
+    const unsigned char *src = uniform_ptr(wts + (size_t)T * G::TILE);
+    const int dst0 = G::WRING_OFF + slot * G::TILE + wave_u * 1024;
 #pragma unroll
     for (int j = 0; j < 2; j++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + woff[j]),
                                          (__attribute__((address_space(3))) void *)(lds + dst0 + j * 8192), 16, 0, 0);
 }
 
-// piece j (0..4) of activation chunk `chunk` into LDS chunk buffer `buf`: wave w moves rows 32 w .. 32 w + 31 (5 KiB of the
-// padded image = 5 pieces of 1 KiB; lanes that fall on a row's padding re-read its first 16 bytes)
+// piece j (0 .. APIECES - 1) of activation chunk `chunk` into LDS chunk buffer `buf`.  NB 4: wave w moves rows 32 w .. 32 w + 31
+// (5 KiB of the padded image = 5 pieces); NB 2: the wave moves pieces w, w + 8, w + 16 of the 20-KiB image (pieces 20 .. 23
+// re-read the last row into the buffer's tail).  Lanes that fall on a row's padding re-read its first 16 bytes.
+template <class G>
 __device__ __forceinline__ void layer_stage_act(const unsigned char *act, lds_byte *lds, int chunk, int buf, int j,
                                                 unsigned voff, int wave_u)
 {
-    const unsigned char *src = uniform_ptr(act + (size_t)chunk * LayerGeo::CHUNK_BYTES);
+    const unsigned char *src = uniform_ptr(act + (size_t)chunk * G::CHUNK_BYTES);
+    const int dst = G::NB == 4 ? buf * G::ABUF + wave_u * 5120 + j * 1024 : buf * G::ABUF + (wave_u + 8 * j) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff),
-                                     (__attribute__((address_space(3))) void *)(lds + buf * LayerGeo::ACHUNK + wave_u * 5120 + j * 1024),
-                                     16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)(lds + dst), 16, 0, 0);
 }
 
 // The input planes of the listed / all boards as the first layer's activation image: [workgroup][chunk 4][row 256][hi 32 | lo
@@ -101,31 +114,31 @@ __device__ __forceinline__ void layer_stage_act(const unsigned char *act, lds_by
 // lo adds exact zeros -- 1/123 of the tower's MFMAs for one kernel body less).
 //   planes  BITS: 128 plane bitboards per board (u64 [n][128], bit sq of plane c = channel c on square sq; row 0 of the planes
 //           is rank 8);  else fp16 [n][64][128]
-//   list    IDX: int32 [LIST_HEADER + n], [0] = listed boards, [LIST_HEADER + k] = the board workgroup k / 4 holds at slot k % 4
+//   list    IDX: int32 [LIST_HEADER + n], [0] = listed boards, [LIST_HEADER + k] = the board workgroup k / NB holds at slot k % NB
 //           (a list that does not fill its last workgroup is padded with its last entry)
-template <int BITS, int IDX>
+template <int BITS, int IDX, int NB = 4>
 __global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__restrict__ planes, unsigned char *__restrict__ act_out,
                                                       const int *__restrict__ list)
 {
-    typedef LayerGeo G;
+    typedef LayerGeoT<NB> G;
     const int tid = threadIdx.x;
-    int rows[4];
+    int rows[NB];
 #pragma unroll
-    for (int b = 0; b < 4; b++) rows[b] = blockIdx.x * 4 + b;
+    for (int b = 0; b < NB; b++) rows[b] = blockIdx.x * NB + b;
     if constexpr (IDX) {
         const int listed = list[0];
-        if ((int)blockIdx.x * 4 >= listed) return;
+        if ((int)blockIdx.x * NB >= listed) return;
 #pragma unroll
-        for (int b = 0; b < 4; b++) rows[b] = list[LIST_HEADER + (rows[b] < listed ? rows[b] : listed - 1)];
+        for (int b = 0; b < NB; b++) rows[b] = list[LIST_HEADER + (rows[b] < listed ? rows[b] : listed - 1)];
     }
     unsigned char *out = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NB; k++) {
         const int item = k * 512 + tid;                 // (board, position, 16 channels)
         const int b = item >> 9, p = (item >> 3) & 63, c = item & 7;
         int row = rows[0];
 #pragma unroll
-        for (int bb = 1; bb < 4; bb++) row = b == bb ? rows[bb] : row;
+        for (int bb = 1; bb < NB; bb++) row = b == bb ? rows[bb] : row;
         u32x4 v0, v1;
         if constexpr (BITS) {
             const int sq = p ^ 56;
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__res
 // k_trunk_x16 leaves them); 4: as 3, and the trunk's output to out f32 [n][64][256] (tests; its own instance so that the
 // product's last layer carries neither the branch nor the registers).
 // IDX: the launch covers the list's boards (k_layer_expand); a workgroup beyond it leaves at once; head_out rows by the list.
-template <int CHUNKS, int KIND, int IDX>
+template <int CHUNKS, int KIND, int IDX, int NB = 4>
 __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__restrict__ act_in,
                                                        const unsigned char *__restrict__ wts,
                                                        const float *__restrict__ bias,
@@ -169,10 +182,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
                                                        const float *__restrict__ head_w, const float *__restrict__ head_b,
                                                        float *__restrict__ head_out, float *__restrict__ out)
 {
-    typedef LayerGeo G;
+    typedef LayerGeoT<NB> G;
     typedef Geo16<256, 1, 1> WG;                        // weight plane order (row_channel, wswz, chan_of)
     static_assert(CHUNKS == 4 || CHUNKS == 8, "128 input planes or 256 channels");
-    constexpr int PT = 4, CT = 8, HC = 4;               // position blocks, channel blocks, channel blocks per half
+    static_assert(NB == 4 || !(CRL_LAYER_DMA_HALF), "the loader-half experiment is written for four boards");
+    constexpr int PT = 4, CT = G::CT, HC = CT / 2;      // position blocks, channel blocks, channel blocks per half
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];
@@ -180,29 +194,31 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     const int lds_base = (int)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int board = wave >> 1, obase = 128 * (wave & 1);
+    const int board = wave / G::WPB, obase = 16 * CT * (wave % G::WPB);
     const int r = lane & 15, q = lane >> 4;
     int listed = 0;
     if constexpr (IDX) {
         listed = __builtin_amdgcn_readfirstlane(list[0]);
-        if ((int)blockIdx.x * 4 >= listed) return;     // before any DMA or barrier: the whole workgroup leaves
+        if ((int)blockIdx.x * NB >= listed) return;    // before any DMA or barrier: the whole workgroup leaves
     }
     const unsigned char *act = act_in + (size_t)blockIdx.x * G::ACT_WG_BYTES;     // (the stem's image fills half a slot)
 
-    // per-lane source offsets of the five activation pieces of a chunk
-    unsigned voff[5];
+    // per-lane source offsets of the wave's activation pieces of a chunk (16-byte unit g of the padded image = row g / 10,
+    // unit g % 10 of the row; units 8, 9 are padding)
+    unsigned voff[G::APIECES];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int g = j * 64 + lane, rl = g / 10, col = g % 10;
-        voff[j] = (unsigned)((wave * 32 + rl) * G::GROW + (col < 8 ? col : 0) * 16);
+    for (int j = 0; j < G::APIECES; j++) {
+        const int g = NB == 4 ? wave * 320 + j * 64 + lane : (wave + 8 * j) * 64 + lane;
+        const int row = g / 10 < G::ROWS ? g / 10 : G::ROWS - 1, col = g % 10;
+        voff[j] = (unsigned)(row * G::GROW + (col < 8 ? col : 0) * 16);
     }
 
     // ---- prologue: chunk 0, the planes of taps 0 and 1, zero rows
 #pragma unroll
-    for (int j = 0; j < 5; j++) layer_stage_act(act, lds, 0, 0, j, voff[j], wave_u);
+    for (int j = 0; j < G::APIECES; j++) layer_stage_act<G>(act, lds, 0, 0, j, voff[j], wave_u);
     const unsigned woff[2] = {(unsigned)(tid * 16), (unsigned)(8192 + tid * 16)};
 #pragma unroll
-    for (int T = 0; T < 4; T++) layer_stage_w(wts, lds, T, T, woff, wave_u);
+    for (int T = 0; T < 4; T++) layer_stage_w<G>(wts, lds, T, T, woff, wave_u);
     for (int i = tid; i < G::ZERO_BYTES / 16; i += 512)
         *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         constexpr int shift = 8 * dy + dx;
         // (opaque per call: the addresses of all nine taps are loop invariants, and hipcc would otherwise compute the
         // 72 of them once in front of the chunk loop and spill them)
-        int bb = base0 + buf * G::ACHUNK, rr = r;
+        int bb = base0 + buf * G::ABUF, rr = r;
         asm volatile("" : "+v"(bb), "+v"(rr));
         const int zrow = zero_q + ((rr + shift) & 15) * G::AROW;
         const int inb = bb + shift * G::AROW;
@@ -408,13 +424,13 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
 #else
         {
             const int un = u + 2 < CHUNKS * G::TAPS ? u + 2 : CHUNKS * G::TAPS - 1;
-            layer_stage_w(wts, lds, 2 * un, 2 * P, woff, wave_u);
-            layer_stage_w(wts, lds, 2 * un + 1, 2 * P + 1, woff, wave_u);
+            layer_stage_w<G>(wts, lds, 2 * un, 2 * P, woff, wave_u);
+            layer_stage_w<G>(wts, lds, 2 * un + 1, 2 * P + 1, woff, wave_u);
         }
-        if constexpr (t < 5) {
+        if constexpr (t < G::APIECES) {
             // (the buffer of chunk c + 1 was last read in chunk c - 1, whose last barrier is behind us)
             const int cn = c + 1 < CHUNKS ? c + 1 : CHUNKS - 1;
-            layer_stage_act(act, lds, cn, (c + 1) & 1, t, voff[t < 5 ? t : 0], wave_u);
+            layer_stage_act<G>(act, lds, cn, (c + 1) & 1, t, voff[t < G::APIECES ? t : 0], wave_u);
         }
 #endif
 #if defined(CRL_LAYER_STAMPS)
@@ -453,15 +469,17 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
 
     // ---- epilogue: a lane holds, per (pt, g), the 8 consecutive channels obase + 32 g + 8 q .. + 7 of position 16 pt + r
     unsigned char *outp = act_out + (size_t)blockIdx.x * G::ACT_WG_BYTES;
-    float part[PT][3];                                  // KIND 3: partial sums of the three head convolutions
+    // KIND >= 3: the three 1x1 head convolutions.  A position's 256 channels live in 8 groups of 32 (one per (wave, g)) x 4 lane
+    // quarters: 32 partial sums per output, parked in LDS and added in a fixed order that does not depend on the geometry
+    // (no float atomics: reproducible, and the same bits at 4 and at 2 boards per workgroup).  The LDS is free once EVERY wave
+    // is past its last fragment read: the barrier below.
+    constexpr int NC = 32;
+    __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
     if constexpr (KIND >= 3) {
         // (opaque from here on: the head weights are loop invariants of the epilogue; hipcc would otherwise load all 96 of
         // a lane's values in front of the tap loop and spill accumulators to keep them)
         asm volatile("" : "+s"(head_w), "+s"(out));
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) part[pt][k] = 0.f;
+        __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
     for (int g = 0; g < CT / 2; g++)
@@ -491,13 +509,15 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
                 for (int k = 0; k < 3; k++) {
                     const f32x4 wa = *reinterpret_cast<const f32x4 *>(head_w + k * G::F + o0);
                     const f32x4 wb = *reinterpret_cast<const f32x4 *>(head_w + k * G::F + o0 + 4);
+                    float part = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) part[pt][k] += o[0][j] * wa[j];
+                    for (int j = 0; j < 4; j++) part += o[0][j] * wa[j];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) part[pt][k] += o[1][j] * wb[j];
+                    for (int j = 0; j < 4; j++) part += o[1][j] * wb[j];
+                    scratch[(((board * 64 + 16 * pt + r) * 3) + k) * NC + ((obase >> 5) + g) * 4 + q] = part;
                 }
                 if constexpr (KIND == 4) {
-                    float *op = out + (((size_t)blockIdx.x * 4 + board) * 64 + 16 * pt + r) * G::F + o0;
+                    float *op = out + (((size_t)blockIdx.x * NB + board) * 64 + 16 * pt + r) * G::F + o0;
                     *reinterpret_cast<f32x4 *>(op) = f32x4{o[0][0], o[0][1], o[0][2], o[0][3]};
                     *reinterpret_cast<f32x4 *>(op + 4) = f32x4{o[1][0], o[1][1], o[1][2], o[1][3]};
                 }
@@ -515,28 +535,17 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
             }
         }
     if constexpr (KIND >= 3) {
-        // a position's 256 channels live in 2 waves x 4 lane quarters x ... : 8 partial sums per output, added in a fixed
-        // order (no float atomics: results are reproducible); the LDS is free (every wave is past its last fragment read
-        // once it is past the barrier below)
-        constexpr int NC = 8;
-        __builtin_amdgcn_s_barrier();
-        __attribute__((address_space(3))) float *scratch = (__attribute__((address_space(3))) float *)lds;
-#pragma unroll
-        for (int pt = 0; pt < PT; pt++)
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                scratch[(((board * 64 + 16 * pt + r) * 3) + k) * NC + (wave & 1) * 4 + q] = part[pt][k];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int i = tid; i < G::ROWS * 3; i += 512) {
             const int k = i % 3, bp = i / 3;
             float v = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; c++) v += scratch[i * NC + c];      // fixed order
+            for (int c = 0; c < NC; c++) v += scratch[i * NC + c];      // fixed order: channel group major, lane quarter minor
             v += head_b[k];
-            size_t gb = (size_t)blockIdx.x * 4 + (bp >> 6);
+            size_t gb = (size_t)blockIdx.x * NB + (bp >> 6);
             if constexpr (IDX) {
-                const int kk = (int)blockIdx.x * 4 + (bp >> 6);
+                const int kk = (int)blockIdx.x * NB + (bp >> 6);
                 gb = (size_t)list[LIST_HEADER + (kk < listed ? kk : listed - 1)];
             }
             const int pos = bp & 63;

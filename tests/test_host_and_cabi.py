@@ -407,7 +407,7 @@ def test_trunk_kernels_never_read_a_register_with_an_lds_read_in_flight(device_a
                        capture_output=True, text=True)
     kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
     # every dispatched k_trunk_x16<F, NB, BITS, PAIR, GROUP, SPLIT, IDX> + the layer-wise k_layer_conv<CHUNKS, KIND, IDX>
-    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 9, r.stdout
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 18, r.stdout
     assert r.returncode == 0 and all(l.endswith(": ok") for l in kernels), r.stdout
 
 
@@ -437,7 +437,7 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
     kernels = [l for l in r.stdout.splitlines() if l.startswith(("k_trunk_x16<", "k_layer_conv<"))]
     # (round 5: also the layer-wise convolution kernels of csrc/tower_layer.hpp, one whole convolution each: 72 taps,
     # the two-buffer activation chunks and the four-slot plane ring with its ONE barrier per tap)
-    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 9, r.stdout + r.stderr
+    assert sum(l.startswith("k_trunk_x16<") for l in kernels) >= 18 and sum(l.startswith("k_layer_conv<") for l in kernels) >= 18, r.stdout + r.stderr
     assert r.returncode == 0 and all(": ok " in l for l in kernels), r.stdout
     for l in kernels:                                        # the emulation really ran the pipeline
         stats = eval(l.split(": ok ", 1)[1])
@@ -445,7 +445,7 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
 
 
 @pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0,0", "64,2,1,0,0,0,0,0", "64,4,1,0,0,1,0,0", "128,2,1,0,1,0,1,0",
-                                    "layer:8,1,0"])
+                                    "layer:8,1,0,4", "layer:8,2,1,2"])
 def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     """Negative controls of the emulation: loosening a steady-state ``vmcnt`` wait by one, removing a tile
     barrier and loosening a fragment ``lgkmcnt`` wait by one must each be reported (pair ring, plain ring,
@@ -454,12 +454,13 @@ def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     family = "k_layer_conv" if kernel.startswith("layer:") else "k_trunk_x16"
     kernel = kernel.split(":")[-1]
     seg = {(f, t): sg for f, t, sg in chk.kernels_of(device_asm)}[(family, kernel)]
-    kernarg = chk.layer_kernarg(int(kernel.split(",")[1]), False) if family == "k_layer_conv" else None
+    indexed = family == "k_layer_conv" and kernel.split(",")[2] == "1"     # a listed launch: one listed board + its padding
+    kernarg = chk.layer_kernarg(int(kernel.split(",")[1]), indexed) if family == "k_layer_conv" else None
 
     def run(lines):
         ins, labels = chk.parse_kernel(lines)
         try:
-            return chk.check_workgroup(ins, labels, 1, kernarg=kernarg)[0]
+            return chk.check_workgroup(ins, labels, 1, kernarg=kernarg, listed=1 if indexed else None)[0]
         except chk.EmuError as e:
             return ["stopped: %s" % e]
 

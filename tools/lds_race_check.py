@@ -450,6 +450,13 @@ class Wave(object):
             self.sset(t[0], ex, 2)
             self.sset("exec", ex & a, 2)
             self.scc = int((ex & a) != 0)
+        elif op == "s_or_saveexec_b64":
+            ex, a = g("exec", 2), g(t[1], 2)
+            if a is None:
+                raise EmuError("EXEC from an unknown mask: " + text)
+            self.sset(t[0], ex, 2)
+            self.sset("exec", ex | a, 2)
+            self.scc = int((ex | a) != 0)
         elif op.startswith("s_load_dword") or op.startswith("s_buffer_load"):
             n = {"s_load_dword": 1, "s_load_dwordx2": 2, "s_load_dwordx4": 4, "s_load_dwordx8": 8, "s_load_dwordx16": 16}[op]
             base, off = g(t[1], 2), _imm(t[2]) if len(t) > 2 else 0
