@@ -32,7 +32,8 @@
 // 562.9 / 608.4 us inside a C5 bench (profiles/r05); k_trunk_x16<256, 1, SPLIT> took 0.82 ms per convolution.
 // Accumulation order per output: chunk-major, tap, (hi.Whi, lo.Whi, hi.Wlo) -- NOT the order of k_trunk_x16 (tap-major): the
 // library runs ONE arithmetic per (filters, mode), so at 256 filters every split-precision evaluation -- any batch size, the
-// indexed fall-back launch of the hybrid mode too -- goes through these kernels.
+// indexed fall-back launch of the hybrid mode too -- goes through these kernels (at four or at two boards per workgroup: the
+// same accumulation order, the same bits).
 #pragma once
 #include "tower_x16.hpp"
 
