@@ -526,3 +526,16 @@ def test_a_truncated_game_is_not_trained_on_after_a_round_trip_through_the_store
     back = records.loads(records.dumps(recs))                      # what a later run reads from gameplays.json
     assert [b.truncated for b in back] == [False] * 4 and back[1].result is None
     assert [r.game_id for r in trainable_records(back)] == [0, 3]
+
+
+def test_board_list_header_is_one_number_in_the_header_the_kernels_and_the_binding():
+    """The hybrid mode's board list is int32 [CRL_LIST_HEADER + n]: the header's define, the kernels' LIST_HEADER
+    (csrc/tower_common.hpp) and the ctypes binding's constant must be the same number (round 5 widened the header from 2 to 4
+    words for the 64-bit running total)."""
+    from chessrl_amd import _lib
+    header = open(os.path.join(ROOT, "include", "chessrl_hip.h")).read()
+    common = open(os.path.join(ROOT, "chessrl_amd", "csrc", "tower_common.hpp")).read()
+    h = int(re.search(r"#define\s+CRL_LIST_HEADER\s+(\d+)", header).group(1))
+    k = int(re.search(r"constexpr int LIST_HEADER = (\d+);", common).group(1))
+    assert h == k == _lib.LIST_HEADER == 4
+    assert int(re.search(r"#define\s+CRL_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.ABI_VERSION
