@@ -132,6 +132,30 @@ int main(int argc, char **argv)
         printf("    check: 3000 sampled outputs vs CPU: max |err| %.3g (hi + lo), %d beyond 2e-5 relative -> %s\n", worst, bad, bad ? "WRONG" : "ok");
         fflush(stdout);
     }
+    {   // proxy for a 128 -> 128 layer-wise convolution at four boards per workgroup: the two-board geometry (wave tile 64 x 64,
+        // six sub-steps of 8 MFMAs) over 4 K-chunks does the same work per wave and writes the same bytes per workgroup; 2048
+        // workgroups instead of 1024, so HALF its time estimates that convolution (its weight planes would be half as large)
+        typedef LayerGeoT<2> G2;
+        for (int mode = 1; mode <= 2; mode++) {
+            kern_t k = mode == 1 ? (kern_t)k_layer_conv<4, 1, 0, 2> : (kern_t)k_layer_conv<4, 2, 0, 2>;
+            CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_BYTES));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            double best = 1e9;
+            for (int round = 0; round < 3; round++) {
+                hipLaunchKernelGGL(k, dim3(boards / 2), dim3(512), G2::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < reps; i++)
+                    hipLaunchKernelGGL(k, dim3(boards / 2), dim3(512), G2::LDS_BYTES, 0, d_act, d_w, d_bias, d_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / reps < best) best = ms / reps;
+            }
+            CK(hipGetLastError());
+            printf("proxy 128-filter layer-wise conv (k_layer_conv<4, %d, 0, 2>, %d boards, 128 in x 256 out): %.4f ms -> a 128 -> 128 convolution ~ %.4f ms\n",
+                   mode, boards, best, best / 2);
+        }
+    }
 #if defined(CRL_LAYER_STAMPS)
     {   // in-kernel cycle stamps (hipcc ... -DCRL_LAYER_STAMPS): per wave [loop, epilogue, vmcnt wait, barrier, DMA requests]
         unsigned long long *d_dbg; const size_t n_dbg = (size_t)n_wg * 8 * 5;
