@@ -568,6 +568,9 @@ class ChessModel(object):
         in both arithmetics and beyond GUARD_TOL the model leaves f16 for AUTO_STRICT -- from the next step on
         (``graph_epoch``: engines capture again).  Returns max |f16 - f16x3| over policy and value, or None when
         there is nothing to guard (a mode asked for by name, a strict mode, the PyTorch tower)."""
+        if self.fused and self.precision == "hybrid":
+            self.margin_check(planes)
+            return None
         if not (self.fused and self.precision == "f16" and self.precision_requested == "auto"):
             return None
         pa, va = self._forward_fused(planes, precision="f16")
@@ -586,6 +589,30 @@ class ChessModel(object):
                 self.precision_probe = dict(self.precision_probe, chosen=self.precision, guard=g["fired"],
                                             reply_margin=self.reply_margin)
         return d
+
+    @torch.no_grad()
+    def margin_check(self, planes):
+        """The same hand-over while the model runs "hybrid": its reply margin is HYBRID_K x the largest
+        |log p_f16 - log p_f16x3| of the PROBE positions, and a run's own positions can differ by more.  Measure
+        that distance on the positions handed over and, where HYBRID_K x it exceeds the margin in force, widen the
+        margin -- in the device float the captured graphs read, so from the very next step and without a
+        re-capture.  A wider margin only lists more boards for the second, f16x3 evaluation; results do not change.
+        Returns the distance measured."""
+        pa, _ = self._forward_fused(planes, precision="f16")
+        pb, _ = self._forward_fused(planes, precision="f16x3")
+        ok = pb > 1e-12
+        dlog = float((pa[ok].log() - pb[ok].log()).abs().max())
+        g = self.guard
+        g["margin_checks"] = g.get("margin_checks", 0) + 1
+        g["margin_positions"] = g.get("margin_positions", 0) + int(planes.shape[0])
+        g["worst_dlog"] = max(g.get("worst_dlog", 0.0), dlog)
+        g.setdefault("margin_at_start", self.reply_margin)
+        if self.HYBRID_K * dlog > self.reply_margin:
+            g["margin_widened"] = g.get("margin_widened", 0) + 1
+            self.reply_margin = self.HYBRID_K * dlog
+            self._publish_reply_margin()
+        g["margin"] = self.reply_margin
+        return dlog
 
     def _publish_reply_margin(self):
         """Write ``reply_margin`` into the device float crl_reply_margin reads (allocated once, rewritten in

@@ -247,7 +247,11 @@ class SelfPlayRunner(object):
             check = getattr(eng.evaluator, "guard_check", None)
             if check is not None and eng.bitplanes:
                 before = getattr(eng.evaluator, "precision", None)
+                margin = getattr(eng.evaluator, "reply_margin", None)
                 d = check(eng.planes_s2)
+                if before == "hybrid" and getattr(eng.evaluator, "reply_margin", None) != margin:
+                    log.info("hybrid reply margin widened from %.3e to %.3e (log-policy distance of f16 on this run's own "
+                             "tree leaves)", margin, eng.evaluator.reply_margin)
                 if d is not None and getattr(eng.evaluator, "precision", None) != before:
                     log.warning("tower precision guard: |f16 - f16x3| = %.2e on this run's own tree leaves (tolerance "
                                 "%.1e): %s -> %s from the next move on", d, eng.evaluator.GUARD_TOL, before,

@@ -158,6 +158,40 @@ def test_the_run_time_guard_takes_an_auto_kept_f16_off_a_net_that_misses_the_bar
     assert soft.precision == "f16" and d is not None and d < soft.GUARD_TOL and soft.guard["positions"] == 256
 
 
+def test_hybrid_reply_margin_follows_the_log_policy_distance_of_the_runs_own_positions():
+    """hybrid's margin is HYBRID_K x a PROBE's largest |log p_f16 - log p_f16x3|.  The same
+    hand-over as the f16 guard measures that distance on the run's own tree leaves and widens the margin where
+    HYBRID_K x it is larger -- in the device float the captured graphs read: no re-capture, never narrower."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    _, planes = _positions()
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+    model = ChessModel(weights=sharp, precision="hybrid")
+    model.HYBRID_MIN_BOARDS = 0                                      # (batches this small would run plain f16x3)
+    probe_margin = model.reply_margin
+    model.reply_margin = probe_margin * 1e-3                         # as if the probe had seen almost no difference
+    model._publish_reply_margin()
+    run = SelfPlayRunner(model, n_parallel=64, sims=8, seed=3, noise=True, max_plies=512)
+    run.GUARD_EVERY = 2
+    epoch = model.graph_epoch
+    for _ in range(2):
+        run.play_move()
+    g = model.guard
+    assert g["margin_checks"] == 1 and g["margin_widened"] == 1 and g["checks"] == 0 and g["fired"] is None
+    assert model.reply_margin == model.HYBRID_K * g["worst_dlog"] > probe_margin * 1e-3
+    assert abs(float(model._reply_margin_dev[0]) - model.reply_margin) <= 1e-6 * model.reply_margin
+    assert model.graph_epoch == epoch and model.precision == "hybrid"
+    wide = model.reply_margin * 1e6                                  # never narrower; and the captured steps read the
+    model.reply_margin = wide                                        # float in place: under this margin every S1 board
+    model._publish_reply_margin()                                    # is a close call
+    model.margin_check(_positions()[0][:256])
+    assert model.reply_margin == wide and model.guard["margin_widened"] == 1
+    listed = model.fallback_boards()
+    run.play_move()
+    assert model.fallback_boards() >= listed + 64 and model.graph_epoch == epoch
+    run.close()
+
+
 def test_precision_modes_are_selectable_and_a_weight_swap_reselects():
     """``precision`` pins a mode; "auto" re-decides when new weights are loaded in place (training
     rounds) and says so through ``graph_epoch`` so that a LockstepEngine re-captures its hipGraph."""
