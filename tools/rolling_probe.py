@@ -25,7 +25,9 @@ SHARE = float(sys.argv[6]) if len(sys.argv) > 6 else 0.2      # of the wall time
 TOWER = [int(x) for x in (sys.argv[7] if len(sys.argv) > 7 else "10x128").split("x")]
 # precision "auto" (what the product runs): the probe decides, and the run-time guard of an auto-kept f16 re-checks it on the
 # run's own tree leaves every 8 move boundaries (rounds 3-4 ran the no-training probe in --precision f16)
-model = ChessModel(blocks=TOWER[0], filters=TOWER[1], precision="auto")
+# CRL_PRECISION / CRL_SEED: another mode or another random-init net (seed 1 is one that auto runs in hybrid)
+model = ChessModel(blocks=TOWER[0], filters=TOWER[1], precision=os.environ.get("CRL_PRECISION", "auto"),
+                   seed=int(os.environ.get("CRL_SEED", "0")))
 START_PRECISION = model.precision
 run = SelfPlayRunner(model, G, S, seed=0, noise=True, total_games=R * N, round_size=N, max_plies=4096)
 t0 = time.time()
@@ -95,4 +97,4 @@ out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "%dx%d %s" % (TOWER[
                "that lie inside the refilled phase show the sustained rate"}
 print(json.dumps(out))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/rolling_probe%s.json" % ("_train" if TRAIN else ""), "w"), indent=1)
+json.dump(out, open("gpurun_out/rolling_probe%s%s.json" % ("_train" if TRAIN else "", os.environ.get("CRL_TAG", "")), "w"), indent=1)
