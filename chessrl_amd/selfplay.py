@@ -411,16 +411,29 @@ class SelfPlayRunner(object):
         """(rounds complete on EVERY rank, is any rank still playing, news counter: the highest of any rank, or
         with news="min" the one every rank has reached) -- as of the last sync."""
         local, active = self.rounds_complete(), bool(self.active().any())
-        mine = int(poll()) if poll is not None else 0
-        if self.world == 1:
+        failure = getattr(self, "poll_failure", None)
+        mine = getattr(self, "_news_mine", 0)
+        if poll is not None and failure is None:
+            try:
+                mine = self._news_mine = int(poll())
+            except Exception as e:                   # e.g. rank 0's background trainer died: the other ranks sit in
+                failure = self.poll_failure = e      # the next all_reduce -- tell them there instead of leaving them
+        if self.world == 1:                          # to the process group's timeout (ADVICE r4)
+            if failure is not None:
+                raise failure
             return local, active, mine
         if moves % sync_every:
             return done, True, getattr(self, "_news_seen", 0)
         import torch
         import torch.distributed as dist
         dev = self.engine.dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([local, -int(active), -mine if news == "max" else mine], dtype=torch.int64, device=dev)
+        t = torch.tensor([local, -int(active), -mine if news == "max" else mine, -int(failure is not None)],
+                         dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if t[3].item() < 0:                          # every rank leaves at the same sync index, non-zero
+            if failure is not None:
+                raise failure
+            raise RuntimeError("another rank reported a failure (its background trainer) in the periodic all_reduce")
         return int(t[0].item()), bool(t[1].item() < 0), int(-t[2].item() if news == "max" else t[2].item())
 
     def close(self):
@@ -763,7 +776,10 @@ def main(argv=None):
                  args.games, runner.sims_run, dt, runner.sims_run / max(dt, 1e-9))
         if not args.no_train:
             if background is not None:
-                background.drain()                    # the last rounds' training (the other ranks wait in sync_news)
+                try:
+                    background.drain()                # the last rounds' training (the other ranks wait in sync_news)
+                except RuntimeError as e:
+                    runner.poll_failure = e           # ... and hear of a failure there
             runner.sync_news(poll, new_weights, news="min" if dp else "max")
             if background is not None:
                 background.close()

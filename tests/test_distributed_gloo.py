@@ -318,6 +318,70 @@ def test_ranks_keep_playing_while_rank_0_trains_in_the_background(world):
     assert len(loads1) >= 2 and loads1[0][2] < got[1][4], (loads1, got[1][4])
 
 
+def _failing_trainer_worker(rank, world, port, q):
+    """As _async_train_worker, but rank 0's trainer dies on its second round."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import BackgroundTrainer, SelfPlayRunner
+    N, R = 2 * world, 50                                           # far more rounds than the run will see
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
+    run._round_done, run.finished = {}, []
+    mine = [g for g in range(N * R) if g % world == rank]
+    finish_at = {g: 4 * (k + 1) for k, g in enumerate(mine)}
+    state = {"move": 0}
+    last = max(finish_at.values())
+    run.active = lambda: np.array([state["move"] < last])
+
+    def play_move():
+        state["move"] += 1
+        time.sleep(0.01)
+        for g, m in finish_at.items():
+            if m == state["move"]:
+                run.finished.append(records.GameRecord(g, [1, 2, 3], 0, True))
+                run._round_done[g // N] = run._round_done.get(g // N, 0) + 1
+
+    run.play_move = play_move
+
+    def train(w, recs):
+        if w["w"][0] >= 1:
+            raise ValueError("bad round")
+        return dict(w, w=w["w"] + 1), [{"loss": 0.0}]
+
+    bg = BackgroundTrainer({"w": np.zeros(1, np.float32)}, train_fn=train) if rank == 0 else None
+    t0 = time.time()
+    try:
+        run.run_rolling(R, on_round=lambda r, recs: bg.submit(r, recs) if bg is not None else None, sync_every=2,
+                        poll=lambda: bg.ready() if bg is not None else 0, on_news=lambda k: None)
+        q.put((rank, "finished", state["move"], time.time() - t0))
+    except RuntimeError as e:
+        q.put((rank, str(e) + " / " + str(e.__cause__), state["move"], time.time() - t0))
+    dist.destroy_process_group()
+
+
+def test_a_failed_background_trainer_ends_every_rank_at_the_same_sync_index():
+    """rank 0's trainer thread dies while the other ranks keep playing -- they used to sit in the next
+    all_reduce until the process group's timeout.  The periodic all_reduce carries a failure word: every rank
+    raises at the same sync index, the failing one with its own exception as the cause."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39700 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_failing_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=120) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "background trainer failed" in got[0][0] and "bad round" in got[0][0], got
+    assert "another rank reported a failure" in got[1][0], got
+    assert got[0][1] == got[1][1] and got[0][1] < 200, got           # the same move, long before the games run out
+    assert max(got[0][2], got[1][2]) < 30
+
+
 def test_background_trainer_trains_in_order_and_surfaces_its_errors():
     """BackgroundTrainer (one process): rounds are trained in submission order, each from the weights the
     previous one produced; ``ready`` counts finished weight sets; an exception in the trainer thread is raised
