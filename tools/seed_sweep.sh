@@ -5,14 +5,17 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 SEEDS=${1:-"0 1 2 3 4 5 6 7"}
+EXTRA=${EXTRA:-}        # e.g. EXTRA="--blocks 20 --filters 256" TAG=c5 for the same sweep at another configuration
+TAG=${TAG:-c3}
 mkdir -p gpurun_out/seed_sweep
 for s in $SEEDS; do
-  python bench.py --seed $s --steps 20 --warmup 5 --cpu-seconds 1 --strict-steps 0 > gpurun_out/seed_sweep/bench_c3_seed$s.json 2> /dev/null
+  python bench.py --seed $s --steps 20 --warmup 5 --cpu-seconds 1 --strict-steps 0 $EXTRA > gpurun_out/seed_sweep/bench_${TAG}_seed$s.json 2> /dev/null
 done
-python - <<'PY'
-import glob, json
+TAG=$TAG EXTRA="$EXTRA" python - <<'PY'
+import glob, json, os
+TAG, EXTRA = os.environ["TAG"], os.environ["EXTRA"]
 rows = []
-for f in sorted(glob.glob("gpurun_out/seed_sweep/bench_c3_seed*.json")):
+for f in sorted(glob.glob("gpurun_out/seed_sweep/bench_%s_seed*.json" % TAG)):
     d = json.load(open(f))
     c, p, r = d["config"], d["tower_error_vs_fp32"], d["roofline"]
     rows.append({"seed": int(f.split("seed")[-1].split(".")[0]), "probe": c["tower_precision_probe"], "mode": c["tower_precision"],
@@ -21,6 +24,6 @@ for f in sorted(glob.glob("gpurun_out/seed_sweep/bench_c3_seed*.json")):
                  "guard": c.get("tower_precision_guard"), "roofline_frac": r["frac"], "launch_ms": r["launch_ms"],
                  "step_fit_ratio": r.get("step_fit", {}).get("ratio")})
     print(rows[-1]["seed"], rows[-1]["mode"], round(rows[-1]["simulations_per_s"]), rows[-1]["vs_fp32"]["dvalue_max"], rows[-1]["guard"])
-json.dump({"what": "bench.py --seed s --steps 20 --warmup 5 at C3 (4096 games, 800 sims/move, 10x128 random init), one line per seed",
-           "rows": rows}, open("gpurun_out/auto_decisions_c3_seeds.json", "w"), indent=1)
+json.dump({"what": "bench.py --seed s --steps 20 --warmup 5 %s (4096 games, 800 sims/move, random init; no extra flags = C3, 10x128), one line per seed" % EXTRA,
+           "rows": rows}, open("gpurun_out/auto_decisions_%s_seeds.json" % TAG, "w"), indent=1)
 PY
