@@ -817,8 +817,10 @@ int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int b
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_kernel_name: bad argument");
     if (trunk_is_layerwise(filters, flags)) {
         // one forward = k_layer_expand + the stem + 2 launches per block; the block convolutions dominate
-        snprintf(buf, (size_t)buf_len, "k_layer_conv<8, 1|2|3, 0> (+ k_layer_conv<4, 0, 0>, k_layer_expand<%d, 0>)",
-                 (flags & CRL_TRUNK_BITPLANES) ? 1 : 0);
+        // (named as rocprofv3 prints them: <CHUNKS, KIND, IDX, NB>; NB as layer_trunk_forward picks it)
+        const int nb = n_boards <= 512 ? 2 : 4;
+        snprintf(buf, (size_t)buf_len, "k_layer_conv<8, 1|2|3, 0, %d> (+ k_layer_conv<4, 0, 0, %d>, k_layer_expand<%d, 0, %d>)",
+                 nb, nb, (flags & CRL_TRUNK_BITPLANES) ? 1 : 0, nb);
         return CRL_OK;
     }
     const TrunkPick pk = trunk_pick(filters, n_boards, flags & CRL_TRUNK_SPLIT);

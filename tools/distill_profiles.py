@@ -42,7 +42,7 @@ for tag, shape in shapes.items():
         summary[short + " @ " + shape] = {"FETCH_SIZE_KB": f[k][0], "WRITE_SIZE_KB": w[k][0]}
 # the layer-wise split-precision trunk of 256 filters (csrc/tower_layer.hpp) is 1 + 1 + 2 x blocks launches per forward:
 # traffic per FORWARD = the sum over its kernels, keyed by the name crl_trunk_kernel_name reports for that path
-LAYER_NAME = "k_layer_conv<8, 1|2|3, 0> (+ k_layer_conv<4, 0, 0>, k_layer_expand<1, 0>)"
+LAYER_NAME = "k_layer_conv<8, 1|2|3, 0, 4> (+ k_layer_conv<4, 0, 0, 4>, k_layer_expand<1, 0, 4>)"
 for tag in ("trunk256x3",):
     pf, pw = os.path.join(SRC, tag + "_FETCH_SIZE.csv"), os.path.join(SRC, tag + "_WRITE_SIZE.csv")
     if not os.path.exists(pf):
