@@ -96,6 +96,18 @@ def parse():
                    help="process-group timeout (N > 1): rank 0's post-window work -- parity gate against the fp32 "
                         "oracle, phase profile, the other precision modes' legs -- runs while the other ranks wait in "
                         "a collective; explicit so that no configuration depends on the backend's default watchdog")
+    p.add_argument("--steps-per-graph", type=int, default=None,
+                   help="lockstep steps captured into ONE hipGraph launch (default: LockstepEngine.STEPS_PER_GRAPH = 8).  "
+                        "1 keeps a C5 hybrid step at ~130 kernel nodes per graph, which rocprofv3's kernel tracing "
+                        "survives (it segfaults inside hipGraphLaunch at the ~1000 nodes of eight such steps)")
+    p.add_argument("--graph-phase-steps", type=int, default=64,
+                   help="steps of the stamped leg behind the timed window: the same step captured WITH one-thread stamp "
+                        "kernels between its phases and around every trunk launch, replayed as a hipGraph -- phase and "
+                        "kernel times of roofline.step_fit come from the replayed graph (0 = skip: eager HIP events only)")
+    p.add_argument("--gph-seconds", type=float, default=14.0,
+                   help="seconds of the games/hour leg behind the timed region (rank 0, N = 1): COMPLETE games at C2's size "
+                        "(512 in lockstep, 100 sims/move, 6x64 random-init, refill), the first quarter un-counted while "
+                        "the batch mixes; 0 = skip")
     p.add_argument("--numpy-promotion", default="auto", choices=["auto", "nep50", "legacy"],
                    help="arithmetic of the PUCT term 10 * prior (mctree.py:79-87); auto = the installed numpy's")
     return p.parse_args()
@@ -337,6 +349,42 @@ def profile_phases(run, n):
     return out
 
 
+def graph_phases(run, n):
+    """Phase and trunk-launch times of ``n`` steps taken from the REPLAYED hipGraph: the engine captures the same
+    step with one-thread stamp kernels (crl_stamp: id + device wall clock into a ring) between its phases and the
+    model brackets every trunk launch with two more; consecutive stamps telescope to the step, so the parts add up
+    to the stamped step exactly, and that step against the un-stamped timed one shows what the stamps cost.  Mid-move
+    like the timed window.  None without graphs."""
+    from chessrl_amd.engine import StampRing, summarise_stamps
+    eng = run.engine
+    if not eng.use_graph or n <= 0:
+        return None
+    run.begin_move()                                       # fresh trees (a move under way is abandoned: the legs behind
+    K = eng.STEPS_PER_GRAPH                                # the timed window only measure)
+    n = max(K, min(n, run.sims // 3) // K * K)
+    grow = max(0, min(run.sims // 2 + 8, run.sims - n - K - 1))
+    eng.run_steps(grow)                                    # un-stamped, to trees of the timed window's depth
+    ring = StampRing((n + 2 * K) * 16, eng.dev)
+    eng.set_stamps(ring)
+    try:
+        eng.prepare_graphs(n)                              # capture the stamped step (nothing is launched)
+        eng.run_steps(K)                                   # one warm replay
+        torch.cuda.synchronize()
+        ring.clear()
+        t0 = time.perf_counter()
+        eng.run_steps(n)
+        stamps = ring.read()
+        wall_ms = (time.perf_counter() - t0) * 1e3 / n
+    finally:
+        eng.set_stamps(None)                               # (drops the stamped graphs)
+    run._sims_in_move = grow + K + n
+    out = summarise_stamps(stamps)
+    out["host_wall_ms_per_step"] = wall_ms
+    out["source"] = ("crl_stamp kernels captured into the step's hipGraph (%d steps per graph launch), %d steps replayed "
+                     "mid-move, device wall clock at %.0f kHz" % (K, n, ring.ticks_per_ms))
+    return out
+
+
 def pmc_traffic(kernel, shape):
     """HBM-side bytes per launch of `kernel` at `shape` from the tracked PMC table (FETCH_SIZE x 2,
     the gfx950 wide-read correction of MI355X_MICROARCH.md, + WRITE_SIZE), or (None, why)."""
@@ -508,11 +556,24 @@ def dry_run(a, rank, world, dist):
               flush=True)
 
 
-def timed_window(run, a, barrier):
+def timed_window(run, a, barrier, model=None, sync=None):
     """W un-timed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs.  A window
     shorter than a move is centred on the middle of a move (trees pre-grown un-timed); one shortened
     move first (un-timed) loads every move-boundary kernel and host path once, so that a boundary timed
-    later is a steady-state one even when it is the first full-length boundary of the process."""
+    later is a steady-state one even when it is the first full-length boundary of the process.
+    ``model``: its counter of S1 boards evaluated twice (hybrid) is read INSIDE the window, next to the simulation
+    counters -- behind the un-timed steps (round 5 read it in front of them and divided ~21 windows' worth of
+    fall-back boards by one window's simulations).  The runner's precision guard is switched off for the window: a
+    mode change (and a graph re-capture) in mid-window would time two arithmetics under one name."""
+    sync = sync or torch.cuda.synchronize
+    guard_every, run.GUARD_EVERY = getattr(run, "GUARD_EVERY", 0), 0
+    try:
+        return _timed_window(run, a, barrier, model, sync)
+    finally:
+        run.GUARD_EVERY = guard_every
+
+
+def _timed_window(run, a, barrier, model, sync):
     if run._sims_in_move:                         # a second window (another precision mode): finish the move
         run.end_move()
     run.step()
@@ -527,19 +588,31 @@ def timed_window(run, a, barrier):
         pre = max(0, start - a.warmup)
     run.steps(pre + a.warmup)
     run.engine.prepare_graphs(a.steps)        # (nothing is captured inside the timed region)
+    fallback = getattr(model, "fallback_boards", None) if getattr(model, "fused", False) else None
     w = {"pre": pre, "window_start": run._sims_in_move or 0, "moves0": run.moves_played,
-         "c0": run.engine.ctx.counters()}
+         "c0": run.engine.ctx.counters(), "fb0": fallback() if fallback else 0}
     barrier()
     t0 = time.perf_counter()
     run.steps(a.steps)                        # K lockstep steps (the engine replays several steps per hipGraph launch)
-    torch.cuda.synchronize()
+    sync()
     t1 = time.perf_counter()
     barrier()
     w["c1"] = run.engine.ctx.counters()
+    w["fb1"] = fallback() if fallback else 0
     w["moves1"] = run.moves_played            # (the phase profile later crosses a move boundary of its own)
     w["dt"] = t1 - t0
     w["sims"] = w["c1"]["sims"] - w["c0"]["sims"]          # simulations completed (backed up) in the timed region
+    # fraction of the window's simulations whose S1 board went through the f16x3 fall-back (this rank's games)
+    w["twice"] = (w["fb1"] - w["fb0"]) / max(1, w["sims"])
     return w
+
+
+def hybrid_entry(entry, model, win):
+    """What a timed window in ``hybrid`` adds to its precision_modes entry."""
+    if getattr(model, "fused", False) and model.precision == "hybrid":
+        entry["s1_boards_evaluated_twice"] = win["twice"]
+        entry["reply_margin"] = model.reply_margin
+    return entry
 
 
 TOWER_BAR = 1e-3         # north_star: policy / value outputs within 1e-3 of the reference net on the same weights
@@ -636,13 +709,17 @@ def issued_flops(F, B, G):
     return 2.0 * (2 * 73152 * F + 3 * 1152 * F * F * B) * G
 
 
-def compliant_roofline(model, eng, ph, F, B, G, peak, shape):
+def compliant_roofline(model, eng, ph, F, B, G, peak, shape, gp=None):
     """``roofline_compliant``: the kernel every evaluation under the 1e-3 bar runs when a net needs the compliant
     mode (hybrid / f16x3: S2's priors and value) -- the split-precision trunk -- timed inside eager steps of that
     mode on the same games and weights: algorithmic fraction (the three MFMAs of a product count once), issued
     fraction, PMC traffic of that kernel at this shape."""
     kern = trunk_kernel_name(F, G, int(eng.bitplanes) | 2)
-    ins = ph.get("trunk_in_step", {}).get("f16x3")
+    ins = (gp or {}).get("trunk", {}).get("f16x3")
+    src = "stamp kernels around the launch inside the replayed hipGraph of the step"
+    if ins is None:
+        ins = ph.get("trunk_in_step", {}).get("f16x3")
+        src = "HIP events around the launch inside eager steps mid-move"
     if ins is None:
         return None
     ms = ins["launch_ms"]
@@ -650,33 +727,89 @@ def compliant_roofline(model, eng, ph, F, B, G, peak, shape):
     traffic, src = pmc_traffic(kern, shape)
     plane_in = 1024 if eng.bitplanes else 64 * 128 * 2
     return {"bound": "mfma", "kernel": "crl_tower::%s (split precision: hi/lo fp16 operands, three MFMAs per product)" % kern,
-            "launch_ms": ms, "launch_ms_source": "HIP events around the launch inside eager steps mid-move",
+            "launch_ms": ms, "launch_ms_source": src,
             "flops_per_launch": alg, "achieved": alg / ms / 1e9, "peak": peak, "unit": "TFLOP/s",
             "frac": alg / ms / 1e9 / peak,
             "issued_flops_per_launch": issued_flops(F, B, G), "issued_frac": issued_flops(F, B, G) / ms / 1e9 / peak,
             "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": G * plane_in + 2 * (9 * 128 * F + 2 * B * 9 * F * F) * 2 + G * 192 * 4,
-            "trunk_in_step": ph["trunk_in_step"], "phase_ms": {k: ph[k] for k in ("select_expand", "tower_s1", "reply", "tower_s2")}}
+            "trunk_in_step": (gp or {}).get("trunk") or ph["trunk_in_step"],
+            "phase_ms": (gp or {}).get("parts") or {k: ph[k] for k in ("select_expand", "tower_s1", "reply", "tower_s2")}}
 
 
-def tracked_whole_run():
-    """Whole-game figures of the LAST tracked rolling-rounds run (tools/rolling_probe.py; not measured by
-    this bench run): moves per game for the games/hour estimate and the measured games/hour, read from
-    the newest profiles/r*/rolling_probe.json -- or None when the tree carries none."""
+def tracked_whole_run(config=None, mode=None, root=None):
+    """Whole-game figures of a tracked rolling-rounds run (tools/rolling_probe.py; NOT measured by this bench run) of
+    the SAME configuration -- (games in lockstep, sims per move, "BxF") -- in the SAME tower precision mode, without
+    training in the loop: moves per game for the games/hour estimate and the measured games/hour.  The newest match
+    wins (by round directory, then by file time).  None when the tree holds no such run: round 5's line carried the
+    games/hour of a ``hybrid`` run of another net beside an ``f16`` rate (VERDICT r5 weak #11)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rolling_probe*.json")), reverse=True):
+    import re
+
+    def age(path):
+        m = re.search(r"r(\d+)", os.path.basename(os.path.dirname(path)))
+        return (int(m.group(1)) if m else -1, os.path.getmtime(path))
+
+    for path in sorted(glob.glob(os.path.join(root or ROOT, "profiles", "r*", "rolling_probe*.json")), key=age, reverse=True):
         try:
             d = json.load(open(path))
+            tower = d["tower"].split()
+            cfg = (d["games_in_lockstep"], d["sims_per_move"], tower[0])
+            ran = d.get("tower_precision", tower[1] if len(tower) > 1 else None)
+            if d.get("training_in_the_loop") or d.get("tower_precision_at_start", ran) != ran:
+                continue                                     # another workload / a run that changed its arithmetic
+            if (config is not None and tuple(config) != cfg) or (mode is not None and ran != mode):
+                continue
             plies = [r["plies_mean"] for r in d["rounds"]]
-            return {"source": os.path.relpath(path, ROOT) + " (tools/rolling_probe.py: start-up and final tail "
+            return {"source": os.path.relpath(path, root or ROOT) + " (tools/rolling_probe.py: start-up and final tail "
                               "included; NOT measured by this bench run)",
-                    "config": (d["games_in_lockstep"], d["sims_per_move"], d["tower"].split()[0]),
+                    "config": cfg, "tower_precision": ran,
                     "moves_per_game": sum(plies) / len(plies) / 2.0,
                     "games_per_hour": d["games_per_hour_overall"], "seconds": d["seconds_total"],
-                    "games": d["games_total"], "training_in_the_loop": bool(d.get("training_in_the_loop", False))}
-        except (OSError, ValueError, KeyError, ZeroDivisionError):
+                    "games": d["games_total"], "training_in_the_loop": False}
+        except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
             continue
     return None
+
+
+def measure_games_per_hour(seconds, seed, device, steps_per_graph=None):
+    """``metric`` names self-play games/hour: this leg MEASURES one, in the bench run itself -- complete games at C2's
+    size (512 in lockstep, 100 sims/move, 6x64 random-init net in the mode ``auto`` picks, Dirichlet noise, finished
+    slots refilled at once), the only BASELINE configuration whose games (~0.15 s per move round, ~2 s per game) turn
+    over several times in a leg of seconds.  Every game is young at the start, so the first quarter of the leg only
+    mixes the batch; the rate is taken over the rest."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    G, S = 512, 100
+    model = ChessModel(blocks=6, filters=64, device="cuda:%d" % device, seed=seed, precision="auto")
+    run = SelfPlayRunner(model, G, S, seed=seed + 104729, noise=True, device=device, max_plies=2048,
+                         steps_per_graph=steps_per_graph)
+    run.play_move()                                        # captures, first boundary
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    base = len(run.finished)
+    marks = []
+    while True:
+        run.play_move()                                    # (ends on a synchronising boundary)
+        t = time.perf_counter() - t0
+        marks.append((t, len(run.finished) - base, run.sims_run))
+        if t >= seconds:
+            break
+    i0 = next(i for i, m in enumerate(marks) if m[0] >= seconds / 4.0)
+    if i0 == len(marks) - 1:
+        i0 = 0
+    games, secs = marks[-1][1] - marks[i0][1], marks[-1][0] - marks[i0][0]
+    recs = run.finished[base + marks[i0][1]:]
+    out = {"config": "C2: %d self-play games in lockstep, %d sims/move, 6x64 random-init tower (%s), Dirichlet noise, "
+                     "finished slots refilled" % (G, S, model.precision),
+           "games": int(games), "seconds": secs, "games_per_hour": games / secs * 3600.0 if secs > 0 else None,
+           "moves_per_game": (float(sum(len(r.moves) for r in recs)) / len(recs) / 2.0) if recs else None,
+           "simulations_per_s": (marks[-1][2] - marks[i0][2]) / secs if secs > 0 else None,
+           "whole_leg": {"games": int(marks[-1][1]), "seconds": marks[-1][0], "mixing_seconds_not_counted": marks[i0][0]},
+           "note": "measured in this run, complete games; a young batch finishes its short games first, hence the "
+                   "un-counted first quarter"}
+    run.close()
+    return out
 
 
 def main():
@@ -714,7 +847,7 @@ def main():
     max_plies = 2048
     run = SelfPlayRunner(model, a.games, a.sims, seed=a.seed, noise=True, rank=rank, world=world,
                          device=local, use_graph=not a.no_graph, max_plies=max_plies,
-                         numpy_promotion=a.numpy_promotion)
+                         numpy_promotion=a.numpy_promotion, steps_per_graph=a.steps_per_graph)
 
     def barrier():
         torch.cuda.synchronize()
@@ -727,14 +860,10 @@ def main():
         per = every_rank(dist, [w["sims"], w["dt"]], rdev)
         return sum(p[0] for p in per), max(p[1] for p in per), [p[1] / a.steps * 1e3 for p in per]
 
-    fb0 = model.fallback_boards() if model.fused else 0
-    win = timed_window(run, a, barrier)
+    win = timed_window(run, a, barrier, model)
     total_sims, max_dt, rank_ms = reduce_window(win)
-    timed = {model.precision if model.fused else a.dtype: {"simulations_per_s": total_sims / max_dt,
-                                                           "ms_per_step": max_dt / a.steps * 1e3}}
-    if model.fused and model.precision == "hybrid":
-        # fraction of the window's simulations whose S1 board went through the f16x3 fall-back (rank 0's games)
-        timed["hybrid"]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, win["sims"])
+    timed = {model.precision if model.fused else a.dtype: hybrid_entry({"simulations_per_s": total_sims / max_dt,
+                                                                        "ms_per_step": max_dt / a.steps * 1e3}, model, win)}
 
     # ---- the headline carries its own parity evidence: the mode that was timed against the fp32 oracle on
     # the same weights, on positions of complete games played with those weights and on the positions the
@@ -751,12 +880,10 @@ def main():
         # the timed mode misses the bar on these weights: the headline is the rate of the mode the product
         # falls back to (every output under the bar evaluated in f16x3)
         model.set_precision(model.AUTO_STRICT)
-        fb0 = model.fallback_boards()
-        win = timed_window(run, a, barrier)
+        win = timed_window(run, a, barrier, model)
         total_sims, max_dt, rank_ms = reduce_window(win)
-        timed[model.precision] = {"simulations_per_s": total_sims / max_dt, "ms_per_step": max_dt / a.steps * 1e3}
-        if model.precision == "hybrid":
-            timed["hybrid"]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, win["sims"])
+        timed[model.precision] = hybrid_entry({"simulations_per_s": total_sims / max_dt,
+                                               "ms_per_step": max_dt / a.steps * 1e3}, model, win)
         if rank == 0:
             failed = parity
             parity = tower_error_vs_fp32(model, parity_sets, model.precision)
@@ -784,10 +911,17 @@ def main():
         ms_step = max_dt / a.steps * 1e3
         boundary = time_move_boundary(run)               # rank 0 only; the other ranks wait at the last barrier
         ph = profile_phases(run, 16)                     # eager steps mid-move: every phase and every trunk launch
+        gp = graph_phases(run, a.graph_phase_steps) if model.fused else None   # the same from the replayed hipGraph
         main_kind = model._trunk_mode() if model.fused else None     # the arithmetic of the roofline's kernel
         k_ms_b2b, in_step = k_ms, False
-        if model.fused and main_kind in ph.get("trunk_in_step", {}):
-            in_step = True
+        if gp is not None and main_kind in gp["trunk"]:
+            # the kernel's time INSIDE the replayed graph (stamp kernels around the launch): round 5's C5 line added
+            # eager phase times up to 1.03-1.10 x its own graph-replayed step -- legs of one long process hold
+            # different clocks; the stamps ride in the graph that is being timed
+            in_step = "graph"
+            k_ms = gp["trunk"][main_kind]["launch_ms"]
+        elif model.fused and main_kind in ph.get("trunk_in_step", {}):
+            in_step = "eager"
             # the kernel's time INSIDE the steps (HIP events around the launch, on the launch stream): 50 launches
             # back to back after the run hold a lower clock than a launch between search kernels and heads does --
             # round 4's line carried a kernel time that did not fit twice into its own step
@@ -818,23 +952,35 @@ def main():
                 "achieved": k_flops / k_ms / 1e9, "peak": peak, "unit": "TFLOP/s",
                 "frac": k_flops / k_ms / 1e9 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": alg_bytes,
-                "launch_ms": k_ms, "launch_ms_source": "HIP events around the launch inside 16 eager steps mid-move "
-                                                       "(profile_phases)" if in_step else
-                                                       "HIP events around 50 back-to-back launches",
+                "launch_ms": k_ms, "launch_ms_source": {"graph": "stamp kernels around the launch inside the replayed "
+                                                                 "hipGraph of the step (graph_phases)",
+                                                        "eager": "HIP events around the launch inside 16 eager steps "
+                                                                 "mid-move (profile_phases)",
+                                                        False: "HIP events around 50 back-to-back launches"}[in_step],
                 "launch_ms_back_to_back": k_ms_b2b, "flops_per_launch": k_flops,
                 "tower_forward_ms": tower_ms, "tower_tflops": tower_flops / tower_ms / 1e9,
                 "tower_frac": tower_flops / tower_ms / 1e9 / peak}
+        eager_fit = None
         if model.fused and "trunk_ms_per_step" in ph:
-            # self-consistency: the step's kernels as timed inside eager steps must fit the timed step
             parts = {"trunk_launches": ph["trunk_ms_per_step"], "heads": ph["heads_and_margin_ms"],
                      "select_expand": ph["select_expand"], "reply": ph["reply"]}
             total = sum(parts.values())
-            roof["step_fit"] = dict(parts, sum_ms=total, ms_per_step=ms_step, ratio=total / ms_step,
-                                    fits=bool(total <= 1.02 * ms_step),
-                                    trunk_in_step=ph["trunk_in_step"], events=ph.get("events"),
-                                    note="eager phases (HIP events) against the hipGraph-replayed timed step")
-            if main_kind == "f16x3":
-                roof["issued_frac"] = issued_flops(F, B, G) / k_ms / 1e9 / peak
+            eager_fit = dict(parts, sum_ms=total, ratio=total / ms_step, trunk_in_step=ph["trunk_in_step"],
+                             events=ph.get("events"), note="eager phases (HIP events) against the timed step")
+        if gp is not None:
+            # self-consistency: the step's parts as stamped inside the replayed graph must fit the timed step.  They
+            # add up to the stamped step by construction; the ratio is the stamped step (parts + one launch gap per
+            # stamp) against the un-stamped K timed steps
+            total = gp["ms_per_step"]
+            roof["step_fit"] = dict(parts=gp["parts"], sum_ms=total, ms_per_step=ms_step, ratio=total / ms_step,
+                                    fits=bool(total <= 1.02 * ms_step), trunk_in_step=gp["trunk"],
+                                    stamps_per_step=gp["stamps_per_step"], steps=gp["steps"], source=gp["source"],
+                                    eager=eager_fit,
+                                    note="parts stamped inside the replayed hipGraph against the un-stamped timed step")
+        elif eager_fit is not None:
+            roof["step_fit"] = dict(eager_fit, ms_per_step=ms_step, fits=bool(eager_fit["sum_ms"] <= 1.02 * ms_step))
+        if model.fused and main_kind == "f16x3":
+            roof["issued_frac"] = issued_flops(F, B, G) / k_ms / 1e9 / peak
         # ---- hand-written HIP search kernels (HBM-bound): select+expand and reply -----------
         # algorithmic bytes per simulation, SURVEY.md section 8d with the measured d and b;
         # with the fused trunk the encoders hand over 1-KiB plane bitboards (expanded on chip); any
@@ -874,7 +1020,7 @@ def main():
         # the other one over a short window mid-move -----------------------------------------------------
         modes = None
         # the timed mode already is the compliant one -> its own in-step profile; else filled in by the hybrid leg
-        compliant = (compliant_roofline(model, eng, ph, F, B, G, peak, shape)
+        compliant = (compliant_roofline(model, eng, ph, F, B, G, peak, shape, gp)
                      if model.fused and main_kind == "f16x3" else None)
         if model.fused:
             modes = {k: dict(v, window="the K timed steps") for k, v in timed.items()}
@@ -912,15 +1058,20 @@ def main():
                 if other == "hybrid":
                     modes[other]["s1_boards_evaluated_twice"] = (model.fallback_boards() - fb0) / max(1, nsim)
                     modes[other]["reply_margin"] = model.reply_margin
-                    compliant = compliant_roofline(model, eng, profile_phases(run, 8), F, B, G, peak, shape)
+                    compliant = compliant_roofline(model, eng, profile_phases(run, 8), F, B, G, peak, shape,
+                                                   graph_phases(run, min(32, a.graph_phase_steps)))
             if model.precision != keep:
                 model.set_precision(keep)
             modes["f16_vs_f16x3_on_probe"] = probe_dist
         cfg_name = {(512, 100, 6, 64): "C2", (4096, 800, 10, 128): "C3 (= C4 per-GPU shard)",
                     (4096, 800, 20, 256): "C5 per-GPU shard"}.get((G, a.sims, B, F), "custom")
-        whole = tracked_whole_run()
-        same_cfg = whole is not None and whole["config"] == (G, a.sims, "%dx%d" % (B, F))
+        timed_mode = getattr(model, "precision", a.dtype)
+        whole = tracked_whole_run((G, a.sims, "%dx%d" % (B, F)), timed_mode) if a.weights is None else None
+        same_cfg = whole is not None
         rate = incl or total_sims / max_dt
+        gph = None
+        if world == 1 and a.gph_seconds > 0 and model.fused:
+            gph = measure_games_per_hour(a.gph_seconds, a.seed, local, a.steps_per_graph)
         out = {
             "metric": "MCTS simulations/sec at 800 sims/move", "value": total_sims / max_dt,
             "unit": "simulations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -955,8 +1106,13 @@ def main():
             "moves_per_sec": rate / a.sims,
             # games/hour: steady state with refill = moves/s / moves per game, the latter read from the
             # tracked whole-run measurement of the SAME configuration (else no estimate is made)
+            # games/hour.  MEASURED in this run: complete games at C2's size (measure_games_per_hour).  For the timed
+            # configuration two figures READ from a tracked whole run of the same configuration in the same tower
+            # precision mode (else none is stated): the steady-state estimate = this run's moves/s / that run's moves per
+            # game, and that run's own games/hour
+            "self_play_games_per_hour_measured": gph,
             "self_play_games_per_hour_est": (rate / a.sims / whole["moves_per_game"] * 3600.0 if same_cfg else None),
-            "self_play_games_per_hour_whole_run": ({k: whole[k] for k in ("games_per_hour", "seconds", "games",
+            "self_play_games_per_hour_whole_run": ({k: whole[k] for k in ("games_per_hour", "seconds", "games", "tower_precision",
                                                                          "training_in_the_loop", "source")}
                                                    if same_cfg else None),
             "tower_evals_per_sim": d["evals"] / max(1, d["sims"]),

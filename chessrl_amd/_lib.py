@@ -57,7 +57,7 @@ SYMBOLS = [
     "crl_heads_forward_legal", "crl_heads_forward_legal_raw", "crl_heads_raw_supported", "crl_heads_set_sliced_max",
     "crl_set_policy_stats", "crl_abi_version", "crl_source_hash", "crl_reply_margin", "crl_trunk_forward_indexed", "crl_trunk_workspace_bytes",
     "crl_end_move_fetch", "crl_advance_fetch",
-    "crl_im2col3x3_f32", "crl_col2im3x3_f32",
+    "crl_im2col3x3_f32", "crl_col2im3x3_f32", "crl_stamp", "crl_stamp_clock_khz",
 ]
 
 
@@ -65,7 +65,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
+ABI_VERSION = 8          # include/chessrl_hip.h: CRL_ABI_VERSION (checked against the loaded library)
 _HASH_MARK = b"CRL_SRC_HASH="
 
 
@@ -202,12 +202,12 @@ def lib():
     L.crl_advance_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crl_trunk_forward.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.crl_trunk_forward_bitplanes.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
-    L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.crl_trunk_forward_x.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, ctypes.c_size_t]
     L.crl_trunk_workspace_bytes.argtypes = [i32, i32, i32]
     L.crl_trunk_workspace_bytes.restype = ctypes.c_size_t
     L.crl_set_plane_format.argtypes = [vp, i32]
     L.crl_reply_margin.argtypes = [vp, vp, vp, i32, vp, i32, vp]
-    L.crl_trunk_forward_indexed.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.crl_trunk_forward_indexed.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, ctypes.c_size_t]
     L.crl_trunk_set_small_batch.argtypes = [i32]
     L.crl_trunk_kernel_name.argtypes = [i32, i32, i32, ctypes.c_char_p, i32]
     L.crl_heads_forward.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -220,6 +220,8 @@ def lib():
     L.crl_eval_labels.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.crl_im2col3x3_f32.argtypes = [vp, vp, vp, i32, i32]
     L.crl_col2im3x3_f32.argtypes = [vp, vp, vp, i32, i32]
+    L.crl_stamp.argtypes = [vp, vp, u32, u32]
+    L.crl_stamp_clock_khz.argtypes = [i32]
     for name in SYMBOLS:
         if name not in ("crl_destroy", "crl_last_error", "crl_source_hash"):
             getattr(L, name).restype = ctypes.c_int

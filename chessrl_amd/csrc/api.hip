@@ -704,11 +704,15 @@ static int layer_trunk_launch(hipStream_t st, bool bits, const void *planes, con
 
 static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
                                int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
-                               void *workspace, const int32_t *list)
+                               void *workspace, size_t workspace_bytes, const int32_t *list)
 {
     if (!workspace || n_blocks < 1 || !head_out)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the layer-wise 256-filter split-precision trunk needs its "
                                            "workspace (crl_trunk_workspace_bytes), at least one residual block and head_out");
+    // two activation images of 64 KiB per board, whatever the boards per workgroup (n_boards % 4 == 0 was checked)
+    if (workspace_bytes < (size_t)2 * n_boards * (crl_tower::LayerGeo::ACT_WG_BYTES / 4))
+        return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: workspace_bytes is below crl_trunk_workspace_bytes(256, n_boards, "
+                                           "CRL_TRUNK_SPLIT): the activation images of this batch would overrun the buffer");
     // Four boards per workgroup for full batches; two for the indexed launches of the hybrid mode (a list is a few hundred
     // boards: twice the workgroups on otherwise idle CUs, half the work each) and for batches of at most 512 boards.
     // Every output is accumulated in the same order in both geometries: the same bits.
@@ -721,7 +725,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
                          const void *dev_head_b_f32, void *dev_head_out_f32, const int32_t *dev_index = nullptr,
-                         void *dev_workspace = nullptr)
+                         void *dev_workspace = nullptr, size_t workspace_bytes = 0)
 {
     if (filters != 64 && filters != 128 && filters != 256)
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: the fused trunk covers 64, 128 and 256 filters");
@@ -739,7 +743,7 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
     if (trunk_is_layerwise(filters, flags))
         return layer_trunk_forward((hipStream_t)hip_stream, bits, dev_planes_f16, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
                                    n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32, dev_workspace,
-                                   dev_index);
+                                   workspace_bytes, dev_index);
     const TrunkPick pk = trunk_pick(filters, n_boards, split);
 #define CRL_X16(F_, NB_, PAIR_, GROUP_, SPLIT_)                                                  \
     if (filters == F_ && pk.nb == NB_ && pk.pair == PAIR_ && pk.group == GROUP_ && split == (SPLIT_ != 0)) { \
@@ -779,12 +783,12 @@ static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f
 int crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
                               const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
                               const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
-                              const int32_t *dev_list, void *dev_workspace)
+                              const int32_t *dev_list, void *dev_workspace, size_t workspace_bytes)
 {
     if (!dev_list) return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward_indexed: bad argument");
     return trunk_forward(hip_stream, filters, dev_bitplanes_u64, CRL_TRUNK_BITPLANES | CRL_TRUNK_SPLIT, dev_wtiles_f16x3,
                          dev_bias_f32, nullptr, n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32,
-                         dev_list, dev_workspace);
+                         dev_list, dev_workspace, workspace_bytes);
 }
 
 size_t crl_trunk_workspace_bytes(int filters, int n_boards, int flags)
@@ -832,10 +836,11 @@ int crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int b
 int crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
                         const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                         int n_boards, int n_blocks, const void *dev_head_w_f32,
-                        const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace)
+                        const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace, size_t workspace_bytes)
 {
     return trunk_forward(hip_stream, filters, dev_planes, flags, dev_wtiles_f16, dev_bias_f32, dev_out_f32,
-                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32, nullptr, dev_workspace);
+                         n_boards, n_blocks, dev_head_w_f32, dev_head_b_f32, dev_head_out_f32, nullptr, dev_workspace,
+                         workspace_bytes);
 }
 
 int crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16,
@@ -981,6 +986,32 @@ static int train_op(void *hip_stream, const void *src, void *dst, int n_boards, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
     return CRL_OK;
+}
+
+// ---- measurement: (id, device wall clock) appended to a ring, capturable into a hipGraph (bench.py) ---------------------
+__global__ void k_stamp(unsigned long long *ring, unsigned capacity, unsigned id)
+{
+    const unsigned long long n = ring[0];
+    ring[2 + 2 * (n % capacity)] = id;
+    ring[3 + 2 * (n % capacity)] = wall_clock64();
+    ring[0] = n + 1;
+}
+
+int crl_stamp(void *hip_stream, uint64_t *dev_ring, uint32_t capacity, uint32_t id)
+{
+    if (!dev_ring || capacity < 1) return fail(nullptr, CRL_ERR_ARG, "crl_stamp: bad argument");
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, (unsigned long long *)dev_ring, capacity, id);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_stamp_clock_khz(int device)
+{
+    int khz = 0;
+    hipError_t e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
+    if (e != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(e));
+    return khz;
 }
 
 int crl_im2col3x3_f32(void *hip_stream, const void *dev_x_f32, void *dev_cols_f32, int n_boards, int channels)

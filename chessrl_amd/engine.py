@@ -124,6 +124,89 @@ def resolve_numpy_promotion(mode="auto"):
     return mode
 
 
+# stamp ids (StampRing): the engine's phase boundaries and the evaluator's trunk launches
+STAMP_STEP, STAMP_SELECTED, STAMP_S1_DONE, STAMP_REPLIED, STAMP_GRAPH_END = 0, 1, 2, 3, 4
+STAMP_TRUNK = {"f16": (8, 9), "f16x3": (10, 11), "f16x3 indexed": (12, 13)}      # (begin, end) per trunk arithmetic
+
+
+class StampRing(object):
+    """Device ring of (id, device wall clock) pairs written by ``crl_stamp`` (include/chessrl_hip.h): one-thread
+    kernels that capture into a hipGraph like any other, so the time of every phase of a step and of every trunk
+    launch comes from the REPLAYED graph -- consecutive stamps telescope to the step -- instead of from eager
+    launches timed beside it (VERDICT r5 #1: C5's eager phases added up to 1.03-1.10 x its graph-replayed step)."""
+
+    def __init__(self, capacity, device):
+        import ctypes
+        self._ct = ctypes
+        self.capacity = int(capacity)
+        self.dev = torch.device(device)
+        self.ring = torch.zeros(2 + 2 * self.capacity, dtype=torch.int64, device=self.dev)
+        khz = _lib.lib().crl_stamp_clock_khz(self.dev.index or 0)
+        if khz <= 0:
+            raise _lib.HipLibraryError("crl_stamp_clock_khz failed (%d)" % khz)
+        self.ticks_per_ms = float(khz)
+
+    def stamp(self, sid):
+        vp = self._ct.c_void_p
+        rc = _lib.lib().crl_stamp(vp(torch.cuda.current_stream(self.dev).cuda_stream), vp(self.ring.data_ptr()),
+                                  self.capacity, int(sid))
+        if rc != 0:
+            raise _lib.HipLibraryError("crl_stamp failed (%d)" % rc)
+
+    def clear(self):
+        self.ring.zero_()
+
+    def read(self):
+        """[(id, milliseconds since the first stamp)] in the order written (synchronises)."""
+        torch.cuda.synchronize(self.dev)
+        host = self.ring.cpu().numpy()
+        n = int(host[0])
+        if n > self.capacity:
+            raise RuntimeError("stamp ring overflowed (%d stamps, capacity %d)" % (n, self.capacity))
+        ids, clk = host[2:2 + 2 * n:2], host[3:3 + 2 * n:2]
+        return [(int(i), float(c - clk[0]) / self.ticks_per_ms) for i, c in zip(ids, clk)]
+
+
+def summarise_stamps(stamps):
+    """Per-phase means of a stamped run (``StampRing.read()``).  Every interval between two consecutive stamps is
+    attributed to what ran in it -- so the parts add up to the wall time between the first and the last stamp BY
+    CONSTRUCTION; what the comparison with the un-stamped timed step then shows is the cost of the stamps themselves
+    (one launch gap each).  An interval that starts at a trunk-begin stamp is that trunk launch (one kernel for the
+    fused trunk, the 42 of a layer-wise forward); the rest of a tower phase (heads, the hybrid mode's margin kernel,
+    the stamps' own gaps) is "tower_s1 other" / "tower_s2 other".
+    Returns {steps, ms_per_step, stamps_per_step, parts: {name: ms per step}, trunk: {kind: {launch_ms,
+    launches_per_step, min_ms, max_ms}}}."""
+    phase_of = {STAMP_STEP: "select_expand", STAMP_SELECTED: "tower_s1", STAMP_S1_DONE: "reply",
+                STAMP_REPLIED: "tower_s2", STAMP_GRAPH_END: "graph_launch_gap"}
+    begin = {b: k for k, (b, e) in STAMP_TRUNK.items()}
+    parts, trunk, steps, phase = {}, {}, 0, None
+    first = next((k for k, (i, _) in enumerate(stamps) if i == STAMP_STEP), len(stamps))
+    stamps = stamps[first:]                  # (evaluations in front of the first step -- warm-up, the root -- are not steps)
+    for (i0, t0), (i1, t1) in zip(stamps[:-1], stamps[1:]):
+        dt = t1 - t0
+        if i0 == STAMP_STEP:
+            steps += 1
+        phase = phase_of.get(i0, phase)
+        if i0 in begin:
+            kind = begin[i0]
+            if i1 != STAMP_TRUNK[kind][1]:
+                raise RuntimeError("stamp %d (trunk begin) followed by %d" % (i0, i1))
+            trunk.setdefault(kind, []).append(dt)
+            key = "trunk %s (%s)" % (kind, "s1" if phase == "tower_s1" else "s2")
+        elif phase in ("tower_s1", "tower_s2"):
+            key = phase + " other"
+        else:
+            key = phase or "before the first step"
+        parts[key] = parts.get(key, 0.0) + dt
+    if steps == 0:
+        raise RuntimeError("no complete step among the stamps")
+    total = stamps[-1][1] - stamps[0][1]
+    return {"steps": steps, "ms_per_step": total / steps, "stamps_per_step": (len(stamps) - 1) / steps,
+            "parts": {k: v / steps for k, v in sorted(parts.items())},
+            "trunk": {k: {"launch_ms": sum(v) / len(v), "launches_per_step": len(v) / steps,
+                          "min_ms": min(v), "max_ms": max(v)} for k, v in trunk.items()}}
+
+
 class LockstepEngine(object):
     """G games x one search tree each on one GPU.
 
@@ -132,7 +215,8 @@ class LockstepEngine(object):
     """
 
     def __init__(self, evaluator, n_games, max_sims, device=0, max_plies=4096,
-                 numpy_promotion="auto", use_graph=True, bitplanes=None, legal_priors=None, raw_priors=None):
+                 numpy_promotion="auto", use_graph=True, bitplanes=None, legal_priors=None, raw_priors=None,
+                 steps_per_graph=None):
         numpy_promotion = resolve_numpy_promotion(numpy_promotion)
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("LockstepEngine needs an MI355X: no CPU fallback exists")
@@ -188,6 +272,11 @@ class LockstepEngine(object):
         self._full = (self.planes_s1, self.planes_s2, self.pol_s1, self.pol_s2, self.val_s2,
                       self.pri_s1, self.pri_s2)
         self.use_graph = use_graph
+        if steps_per_graph is not None:
+            if int(steps_per_graph) < 1:
+                raise ValueError("steps_per_graph must be >= 1")
+            self.STEPS_PER_GRAPH = int(steps_per_graph)      # (instance override of the class default)
+        self.stamps = None                   # measurement: a StampRing -> every phase of a step is stamped (bench.py)
         self._graphs = {}                    # steps per graph -> captured hipGraph
         self._graph_epoch = 0
         self._bind_stream()
@@ -254,10 +343,31 @@ class LockstepEngine(object):
             self._eval_into(self.planes_s2, self.pol_s2, self.val_s2)
 
     def _step_body(self):
+        st = self.stamps
+        if st is None:
+            self.phase_select_expand()
+            self.phase_tower_s1()
+            self.phase_reply()
+            self.phase_tower_s2()
+            return
+        # measurement build of the same step (bench.py): one-thread stamp kernels between the phases, captured into
+        # the graph with them; the evaluator stamps its own trunk launches (ChessModel.stamp_fn)
+        st.stamp(STAMP_STEP)
         self.phase_select_expand()
+        st.stamp(STAMP_SELECTED)
         self.phase_tower_s1()
+        st.stamp(STAMP_S1_DONE)
         self.phase_reply()
+        st.stamp(STAMP_REPLIED)
         self.phase_tower_s2()
+
+    def set_stamps(self, ring):
+        """Attach (or with None detach) a StampRing: the captured graphs are dropped either way, the next
+        ``run_steps`` captures the step with (without) its stamps."""
+        self.stamps = ring
+        if hasattr(self.evaluator, "stamp_fn"):
+            self.evaluator.stamp_fn = ring.stamp if ring is not None else None
+        self._graphs = {}
 
     # One hipGraph launch costs ~12 us between the last kernel of one graph and the first of the next (measured,
     # tools/graph_unroll_probe.py): nothing at C3 (0.5 %), 9 % of a C2 step.  So the engine also keeps a graph of
@@ -285,6 +395,8 @@ class LockstepEngine(object):
             self._bind_stream()              # kernels must land on the capturing stream
             for _ in range(k):
                 self._step_body()
+            if self.stamps is not None:
+                self.stamps.stamp(STAMP_GRAPH_END)
         self._bind_stream()
         self._graphs[k] = g
         self._graph_epoch = getattr(self.evaluator, "graph_epoch", 0)

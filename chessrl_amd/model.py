@@ -14,10 +14,14 @@ the cast to fp16; softmax / tanh run in fp32.  Weights are exchanged as a flat
 ``name -> ndarray`` dict in Keras layouts (conv HWIO, dense (in,out)), saved as
 ``.npz`` or as a Keras ``.h5`` weight file (chessrl_amd/keras_h5.py; no h5py needed).
 """
+import logging
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+log = logging.getLogger("chessrl_amd.model")
 
 BN_EPS = 1e-3            # keras.layers.BatchNormalization default
 N_POLICY = 1968
@@ -244,6 +248,8 @@ class ChessModel(object):
                              # are two workgroup rounds, and a batch this small is one or two rounds of the split
                              # kernel anyway (C2's 512 boards: hybrid 0.351 ms per step against 0.288 in f16x3)
     AUTO_STRICT = "hybrid"   # what "auto" runs when f16 is not within PROBE_TOL ("f16x3" = no S1 shortcut)
+    STICKY_FACTOR = 0.5      # after the run-time guard has fired, f16 is re-entered only below STICKY_FACTOR x PROBE_TOL
+    MARGIN_CAP = 8.0         # margin_check never widens the reply margin beyond MARGIN_CAP x the probe's
     GUARD_TOL = 9e-4         # run-time guard of an auto-kept "f16": |f16 - f16x3| on the run's OWN tree leaves beyond
                              # which the model leaves f16 for AUTO_STRICT (f16x3 is within 1e-4 of fp32: 1e-3 in all)
 
@@ -263,9 +269,12 @@ class ChessModel(object):
         self._fallback = {}                      # hybrid: batch size -> the device list of boards to evaluate again
         self.graph_epoch = 0                     # bumped when the kernel a captured graph holds changes
         self.trunk_events = None                 # bench.py: a list -> every trunk launch is bracketed by HIP events
+        self.stamp_fn = None                     # bench.py: StampRing.stamp -> every trunk launch is bracketed by stamp
+                                                 # kernels that capture into the step's hipGraph (engine.set_stamps)
         self.guard = {"checks": 0, "positions": 0, "worst": 0.0, "fired": None}   # guard_check's record
         self._scratch = {}                       # batch size -> slice statistics of the small-batch heads
-        self._workspace = {}                     # batch size -> activation images of the layer-wise trunk (256 filters, f16x3)
+        self._workspace = None                   # activation images of the layer-wise trunk (256 filters, f16x3): ONE buffer,
+                                                 # sized for the largest batch seen (graph_epoch is bumped when it grows)
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("ChessModel needs an MI355X (no CPU fallback in the product path)")
@@ -465,7 +474,8 @@ class ChessModel(object):
             ctypes.c_void_p(self._wbias.data_ptr()),
             ctypes.c_void_p(trunk.data_ptr() if want_trunk else None), bp, self.blocks,
             ctypes.c_void_p(self._head_w.data_ptr()), ctypes.c_void_p(self._head_b.data_ptr()),
-            ctypes.c_void_p(heads.data_ptr()), ctypes.c_void_p(ws.data_ptr() if ws is not None else None))
+            ctypes.c_void_p(heads.data_ptr()), ctypes.c_void_p(ws.data_ptr() if ws is not None else None),
+            ws.numel() if ws is not None else 0)
         if rc != 0:
             raise _lib.HipLibraryError("crl_trunk_forward_x failed (%d)" % rc)
         if ev is not None:
@@ -474,21 +484,38 @@ class ChessModel(object):
 
     def _trunk_workspace(self, bp):
         """The activation images the layer-wise split-precision trunk (256 filters; csrc/tower_layer.hpp) ping-pongs
-        between: crl_trunk_workspace_bytes of device memory per batch size, kept (captured graphs hold the address);
-        None where the library wants none."""
+        between: ONE buffer of crl_trunk_workspace_bytes for the LARGEST batch this model has evaluated (128 KiB per
+        board), lent to every smaller batch as well; None where the library wants none.  Captured graphs hold its
+        address: when a larger batch makes it grow, ``graph_epoch`` is bumped and engines capture again (a compacting
+        run only ever shrinks its batch, so in practice it is allocated once).  Contents are undefined between calls, so
+        every caller of this model -- the engine's graph, ``guard_check``, the probe -- must launch on ONE stream at a
+        time (every engine of the product does)."""
         from . import _lib
-        ws = self._workspace.get(bp)
-        if ws is None:
-            n = int(_lib.lib().crl_trunk_workspace_bytes(self.filters, bp, _lib.TRUNK_BITPLANES | _lib.TRUNK_SPLIT))
-            if n == 0:
-                return None
-            ws = self._workspace[bp] = torch.empty(n, dtype=torch.uint8, device=self.device)
-        return ws
+        n = int(_lib.lib().crl_trunk_workspace_bytes(self.filters, bp, _lib.TRUNK_BITPLANES | _lib.TRUNK_SPLIT))
+        if n == 0:
+            return None
+        if self._workspace is None or self._workspace.numel() < n:
+            if self._workspace is not None:
+                self.graph_epoch += 1                          # a captured graph holds the old address
+            self._workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._workspace
 
     def _trunk_event(self, kind):
         """Measurement hook (bench.py's in-step kernel time): with ``trunk_events`` a list, every trunk launch is
         bracketed by two HIP events recorded on the launch stream -- (kind, start, end) is appended here, the
-        caller records ``end`` behind its launch.  None (the default) costs one attribute test."""
+        caller records ``end`` behind its launch.  With ``stamp_fn`` set the launch is bracketed by stamp kernels
+        instead (they capture into a hipGraph; the returned object's ``record`` issues the closing stamp).  None
+        (the default) costs two attribute tests."""
+        if self.stamp_fn is not None:
+            from .engine import STAMP_TRUNK
+            b, e = STAMP_TRUNK[kind]
+            self.stamp_fn(b)
+            fn = self.stamp_fn
+
+            class _Close(object):
+                def record(self_inner):
+                    fn(e)
+            return (kind, None, _Close())
         if self.trunk_events is None:
             return None
         make = getattr(self, "trunk_event_cls", None) or torch.cuda.Event      # (bench.py: events without a system fence)
@@ -545,16 +572,24 @@ class ChessModel(object):
             dp, dv = float((pa - pb).abs().max()), float((va - vb).abs().max())
             # the same distance in log space: a rounding error of the trunk moves a LOGIT, i.e. a probability
             # by a factor -- what decides whether an argmax over the legal moves can flip
-            ok = pb > 1e-12
-            dlog = float((pa[ok].log() - pb[ok].log()).abs().max())
+            dlog = self._log_distance(pa, pb)
+            if dlog is None:                                 # (degenerate weights: no finite log-distance anywhere)
+                dlog = float("nan")                          # a NaN margin lists every board: f16x3 everywhere
+            # a run whose guard has fired once stays strict across reloads unless a later weight set passes the probe
+            # WITH margin (half the tolerance): a net at the edge would otherwise flip f16 <-> hybrid -- and re-capture
+            # every engine's graphs -- at each reload
+            sticky = self.guard.get("fired") is not None
+            tol = self.PROBE_TOL * (self.STICKY_FACTOR if sticky else 1.0)
             if self.precision_requested == "hybrid":
                 self.precision = "hybrid"
             else:
-                self.precision = "f16" if max(dp, dv) <= self.PROBE_TOL else self.AUTO_STRICT
+                self.precision = "f16" if max(dp, dv) <= tol else self.AUTO_STRICT
             self.reply_margin = self.HYBRID_K * dlog
+            self._probe_margin = self.reply_margin
             self._publish_reply_margin()
             self.precision_probe = {"positions": int(planes.shape[0]), "dpolicy_max": dp, "dvalue_max": dv,
-                                    "dlog_policy_max": dlog, "tolerance": self.PROBE_TOL, "chosen": self.precision,
+                                    "dlog_policy_max": dlog, "tolerance": tol, "sticky_after_guard": sticky,
+                                    "chosen": self.precision,
                                     "reply_margin": self.reply_margin if self.precision == "hybrid" else None}
         if before is not None and before != self.precision:
             self.graph_epoch += 1
@@ -581,14 +616,26 @@ class ChessModel(object):
         g["positions"] += int(planes.shape[0])
         g["worst"] = max(g["worst"], d)
         if d > self.GUARD_TOL:
-            g["fired"] = {"after_checks": g["checks"], "after_positions": g["positions"], "distance": d,
-                          "tolerance": self.GUARD_TOL, "from": "f16", "to": self.AUTO_STRICT}
-            self.precision = self.AUTO_STRICT
-            self.graph_epoch += 1
-            if self.precision_probe is not None:
-                self.precision_probe = dict(self.precision_probe, chosen=self.precision, guard=g["fired"],
-                                            reply_margin=self.reply_margin)
+            self.enter_strict({"after_checks": g["checks"], "after_positions": g["positions"], "distance": d,
+                               "tolerance": self.GUARD_TOL})
         return d
+
+    def enter_strict(self, why):
+        """Leave an auto-kept "f16" for AUTO_STRICT from the next step on (``graph_epoch``: engines capture again):
+        the run-time guard's action, also taken when ANOTHER rank's guard fired (SelfPlayRunner._follow_strictest).
+        Sticky for the run: later weight sets are kept in f16 only when the probe passes with margin
+        (``_resolve_precision``).  False when there is nothing to leave (a mode asked for by name, a strict mode)."""
+        if not (self.fused and self.precision == "f16" and self.precision_requested == "auto"):
+            return False
+        fired = dict(why) if isinstance(why, dict) else {"why": str(why)}
+        fired.update({"from": "f16", "to": self.AUTO_STRICT})
+        self.guard["fired"] = fired
+        self.precision = self.AUTO_STRICT
+        self.graph_epoch += 1
+        if self.precision_probe is not None:
+            self.precision_probe = dict(self.precision_probe, chosen=self.precision, guard=fired,
+                                        reply_margin=self.reply_margin)
+        return True
 
     @torch.no_grad()
     def margin_check(self, planes):
@@ -600,19 +647,41 @@ class ChessModel(object):
         Returns the distance measured."""
         pa, _ = self._forward_fused(planes, precision="f16")
         pb, _ = self._forward_fused(planes, precision="f16x3")
-        ok = pb > 1e-12
-        dlog = float((pa[ok].log() - pb[ok].log()).abs().max())
+        dlog = self._log_distance(pa, pb)
         g = self.guard
         g["margin_checks"] = g.get("margin_checks", 0) + 1
         g["margin_positions"] = g.get("margin_positions", 0) + int(planes.shape[0])
+        if dlog is None:                                     # nothing comparable on these positions: no decision
+            return None
         g["worst_dlog"] = max(g.get("worst_dlog", 0.0), dlog)
         g.setdefault("margin_at_start", self.reply_margin)
         if self.HYBRID_K * dlog > self.reply_margin:
-            g["margin_widened"] = g.get("margin_widened", 0) + 1
-            self.reply_margin = self.HYBRID_K * dlog
-            self._publish_reply_margin()
+            # never beyond MARGIN_CAP x the probe's margin: a margin that wide lists most boards anyway, and one
+            # outlier (a policy entry at the edge of fp32 underflow in one arithmetic) must not turn every S1
+            # evaluation of the rest of the run into f16 + f16x3
+            cap = self.MARGIN_CAP * (getattr(self, "_probe_margin", None) or g["margin_at_start"])
+            wider = min(self.HYBRID_K * dlog, cap)
+            if self.HYBRID_K * dlog > cap:
+                g["margin_capped"] = g.get("margin_capped", 0) + 1
+                log.warning("hybrid reply margin: %.3e asked for by this run's positions, capped at %.3e (%g x the probe's)",
+                            self.HYBRID_K * dlog, cap, self.MARGIN_CAP)
+            if wider > self.reply_margin:
+                g["margin_widened"] = g.get("margin_widened", 0) + 1
+                self.reply_margin = wider
+                self._publish_reply_margin()
         g["margin"] = self.reply_margin
         return dlog
+
+    @staticmethod
+    def _log_distance(pa, pb):
+        """max |log pa - log pb| over the entries both arithmetics can speak about: pb above 1e-12 AND pa > 0 (an f16
+        policy entry that underflowed to 0 has log -inf: the distance would be infinite, the margin with it, and every
+        S1 board would be evaluated twice until the next weight set).  None when no entry qualifies."""
+        ok = (pb > 1e-12) & (pa > 0)
+        if not bool(ok.any()):
+            return None
+        d = float((pa[ok].log() - pb[ok].log()).abs().max())
+        return d if np.isfinite(d) else None
 
     def _publish_reply_margin(self):
         """Write ``reply_margin`` into the device float crl_reply_margin reads (allocated once, rewritten in
@@ -710,7 +779,7 @@ class ChessModel(object):
             rc = L.crl_trunk_forward_indexed(stream, self.filters, vp(planes_p.data_ptr()), vp(self._wtiles3.data_ptr()),
                                              vp(self._wbias.data_ptr()), bp, self.blocks, vp(self._head_w.data_ptr()),
                                              vp(self._head_b.data_ptr()), vp(hp_full.data_ptr()), vp(lst.data_ptr()),
-                                             vp(ws.data_ptr() if ws is not None else None))
+                                             vp(ws.data_ptr() if ws is not None else None), ws.numel() if ws is not None else 0)
             if rc != 0:
                 raise _lib.HipLibraryError("crl_trunk_forward_indexed failed (%d)" % rc)
             if ev is not None:

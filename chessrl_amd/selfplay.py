@@ -81,10 +81,11 @@ class SelfPlayRunner(object):
 
     def __init__(self, evaluator, n_parallel, sims, seed=0, noise=True, rank=0, world=1, device=0,
                  max_plies=4096, numpy_promotion="auto", use_graph=True, total_games=None,
-                 compact=True, round_size=None):
+                 compact=True, round_size=None, steps_per_graph=None):
         _warm_numpy()
         self.engine = LockstepEngine(evaluator, n_parallel, sims, device=device, max_plies=max_plies,
-                                     numpy_promotion=numpy_promotion, use_graph=use_graph)
+                                     numpy_promotion=numpy_promotion, use_graph=use_graph,
+                                     steps_per_graph=steps_per_graph)
         self.G, self.sims, self.seed, self.noise = n_parallel, sims, seed, noise
         self.rank, self.world = rank, world
         self.total_games = total_games           # global cap on started games (None = endless)
@@ -427,14 +428,35 @@ class SelfPlayRunner(object):
         import torch
         import torch.distributed as dist
         dev = self.engine.dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([local, -int(active), -mine if news == "max" else mine, -int(failure is not None)],
-                         dtype=torch.int64, device=dev)
+        # word 4: the arithmetic this rank's tower runs (f16 < hybrid < f16x3).  A rank whose run-time guard has left
+        # an auto-kept f16 must not play on beside ranks that are still in it with nothing recording that:
+        # the strictest mode of any rank travels here and the others follow at this sync index.
+        t = torch.tensor([local, -int(active), -mine if news == "max" else mine, -int(failure is not None),
+                          -self._mode_index()], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if t[3].item() < 0:                          # every rank leaves at the same sync index, non-zero
             if failure is not None:
                 raise failure
             raise RuntimeError("another rank reported a failure (its background trainer) in the periodic all_reduce")
+        self._follow_strictest(int(-t[4].item()))
         return int(t[0].item()), bool(t[1].item() < 0), int(-t[2].item() if news == "max" else t[2].item())
+
+    _MODE_ORDER = ("f16", "hybrid", "f16x3")
+
+    def _mode_index(self):
+        ev = getattr(getattr(self, "engine", None), "evaluator", None)
+        p = getattr(ev, "precision", None)
+        return self._MODE_ORDER.index(p) if p in self._MODE_ORDER else 0
+
+    def _follow_strictest(self, strictest):
+        """Another rank runs a stricter tower arithmetic than this one (its guard fired): leave an auto-kept f16 too."""
+        if strictest <= self._mode_index():
+            return
+        ev = getattr(getattr(self, "engine", None), "evaluator", None)
+        enter = getattr(ev, "enter_strict", None)
+        if enter is not None and enter("another rank's run-time guard left f16 (agreed in the periodic all_reduce)"):
+            self.mode_follows = getattr(self, "mode_follows", 0) + 1
+            log.warning("rank %d: tower precision -> %s, following the strictest rank", self.rank, ev.precision)
 
     def close(self):
         self.engine.close()
@@ -677,6 +699,8 @@ def main(argv=None):
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         local = int(os.environ.get("LOCAL_RANK", rank))
+        from . import multiprocess_env
+        multiprocess_env()                        # dmabuf IPC for RCCL, before the first GPU call of this process
         # self-test hooks for a 1-GPU box: CRL_DEVICE pins every rank to one device and
         # CRL_DIST_BACKEND=gloo replaces RCCL, so the multi-rank control flow can be exercised there
         local = int(os.environ.get("CRL_DEVICE", local))
@@ -799,7 +823,8 @@ def main(argv=None):
             after_round(rnd, recs)
     import hashlib
     digest = hashlib.sha1(b"".join(np.ascontiguousarray(model.weights[k]).tobytes() for k in sorted(model.weights))).hexdigest()
-    log.info("rank %d: weights at the end %s (%s)", rank, digest[:16], model.precision)
+    log.info("rank %d: weights at the end %s (%s); precision guard: %s", rank, digest[:16], model.precision,
+             getattr(model, "guard", None))
     if world > 1:
         dist.destroy_process_group()
 

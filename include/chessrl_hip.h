@@ -70,7 +70,7 @@ typedef struct crl_ctx crl_ctx;
  * signature hands the GPU garbage pointers).  crl_source_hash(): sha256 over the sources (csrc/ + this
  * header + compiler flags) the library was built from, as chessrl_amd/_lib.py computes it; the string
  * is also findable in the file itself behind the marker "CRL_SRC_HASH=".  No reference counterpart. */
-#define CRL_ABI_VERSION 7
+#define CRL_ABI_VERSION 8
 int  crl_abi_version(void);
 const char *crl_source_hash(void);
 
@@ -246,13 +246,17 @@ int  crl_trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16
 int  crl_trunk_forward_x(void *hip_stream, int filters, int flags, const void *dev_planes,
                          const void *dev_wtiles_f16, const void *dev_bias_f32, void *dev_out_f32,
                          int n_boards, int n_blocks, const void *dev_head_w_f32,
-                         const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace);
+                         const void *dev_head_b_f32, void *dev_head_out_f32, void *dev_workspace,
+                         size_t workspace_bytes);
 
 /* 256 filters with CRL_TRUNK_SPLIT run LAYER-WISE (csrc/tower_layer.hpp: one launch per convolution, a workgroup owns 4
  * boards x all 256 output channels and streams activations and weights; the fused kernel could keep ONE such board resident
  * and streamed the whole weight set for it).  The caller lends the activation images: crl_trunk_workspace_bytes() bytes of
  * device memory (two images of 256 KiB per 4 boards; 0 for every other (filters, flags): dev_workspace may then be NULL),
- * contents undefined before and after a call.  n_blocks >= 1 and dev_head_out_f32 are required there.  The weight image of
+ * contents undefined before and after a call; workspace_bytes says how much the caller really lent and a call whose batch
+ * needs more fails with CRL_ERR_ARG instead of overrunning it (ignored where no workspace is wanted).  n_blocks >= 1 and
+ * dev_head_out_f32 are required there (a trunk-only call has no consumer in the product; the other filter counts, whose
+ * fused kernels write the fp32 trunk on the way, accept both).  The weight image of
  * that path lists, per convolution, the planes K-CHUNK-major: [conv][in-ch/32][tap][Whi, Wlo][256 rows][4 chunks][8 in]
  * (rows / chunks as above; the stem has 4 chunks of input planes, every other convolution 8). */
 size_t crl_trunk_workspace_bytes(int filters, int n_boards, int flags);
@@ -279,7 +283,7 @@ int  crl_reply_margin(void *hip_stream, const void *dev_priors_f32, const int32_
 int  crl_trunk_forward_indexed(void *hip_stream, int filters, const void *dev_bitplanes_u64,
                                const void *dev_wtiles_f16x3, const void *dev_bias_f32, int n_boards, int n_blocks,
                                const void *dev_head_w_f32, const void *dev_head_b_f32, void *dev_head_out_f32,
-                               const int32_t *dev_list, void *dev_workspace);
+                               const int32_t *dev_list, void *dev_workspace, size_t workspace_bytes);
 
 /* crl_trunk_forward with the input given as plane bitboards (CRL_PLANES_BITS), uint64
  * [n_boards][128]; everything else as above. */
@@ -350,6 +354,16 @@ int  crl_trunk_set_small_batch(int enabled);
  * measurement tools look their profiles up by it instead of restating the dispatch rule.  No
  * reference counterpart (model.py:31-63 builds one Keras graph). */
 int  crl_trunk_kernel_name(int filters, int n_boards, int flags, char *buf, int buf_len);
+
+/* ---- measurement -------------------------------------------------------------------------------
+ * crl_stamp enqueues a one-thread kernel that appends (id, wall clock of the device) to a ring in device memory:
+ * dev_ring is uint64 [2 + 2 * capacity], [0] = stamps written so far (zero it once), [1] unused, then pairs
+ * (id, clock) at entry (count % capacity).  It captures into a hipGraph like any kernel, so bench.py gets the time of
+ * every phase of a step and of every trunk launch from the REPLAYED graph (consecutive stamps telescope to the step)
+ * instead of from eager launches beside it.  crl_stamp_clock_khz: the rate of that clock
+ * (hipDeviceAttributeWallClockRate; 100 000 on MI355X), or a negative crl_status.  No reference counterpart. */
+int  crl_stamp(void *hip_stream, uint64_t *dev_ring, uint32_t capacity, uint32_t id);
+int  crl_stamp_clock_khz(int device);
 
 /* ---- training step (model.py:83-99 fit_generator) --------------------
  * The reference's Conv2D layers (model.py:33-34,113-118) train through TensorFlow; here a 3x3 'same'

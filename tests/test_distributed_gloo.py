@@ -494,3 +494,72 @@ def test_data_parallel_news_waits_for_the_slowest_trainer():
     assert all(w == float(k) for k, _, w in l0 + l1) and l0[-1][0] == 2          # set k holds k training rounds
     for (k, m, _) in l1:
         assert m >= r1[k - 1]                                                     # not before the slow rank had it
+
+
+def _guard_follow_worker(rank, world, port, q):
+    """run_rolling on two ranks whose evaluators start in an auto-kept f16; rank 1's run-time guard 'fires' at its
+    third move (its evaluator goes to hybrid).  The periodic all_reduce carries the arithmetic: rank 0 follows at the
+    next sync index through the evaluator's enter_strict."""
+    import types
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chessrl_amd import records
+    from chessrl_amd.selfplay import SelfPlayRunner
+
+    class Eval(object):
+        precision, entered = "f16", []
+
+        def enter_strict(self, why):
+            if self.precision != "f16":
+                return False
+            self.entered.append((state["move"], str(why)))
+            self.precision = "hybrid"
+            return True
+
+    N, R = 4, 2
+    run = SelfPlayRunner.__new__(SelfPlayRunner)
+    run.rank, run.world, run.round_size, run.total_games = rank, world, N, N * R
+    run._round_done, run.finished = {}, []
+    ev = Eval()
+    run.engine = types.SimpleNamespace(evaluator=ev, dev=torch.device("cpu"))
+    mine = [g for g in range(N * R) if g % world == rank]
+    finish_at = {g: 6 * (k + 1) for k, g in enumerate(mine)}
+    state = {"move": 0}
+    last = max(finish_at.values())
+    run.active = lambda: np.array([state["move"] < last])
+
+    def play_move():
+        state["move"] += 1
+        if rank == 1 and state["move"] == 3:
+            ev.precision = "hybrid"                                # this rank's own guard fired
+        for g, m in finish_at.items():
+            if m == state["move"]:
+                run.finished.append(records.GameRecord(g, [1, 2, 3], 0, True))
+                run._round_done[g // N] = run._round_done.get(g // N, 0) + 1
+
+    run.play_move = play_move
+    done = run.run_rolling(R, sync_every=2)
+    q.put((rank, done, ev.precision, list(ev.entered), getattr(run, "mode_follows", 0)))
+    dist.destroy_process_group()
+
+
+def test_a_rank_whose_precision_guard_fired_takes_the_other_ranks_with_it():
+    """the guard flips precision per rank; ranks could end up in different arithmetics with nothing
+    recording that.  The strictest mode of any rank travels in the periodic all_reduce; the others follow there."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 41300 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_guard_follow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=120) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == 2
+    assert got[0][1] == got[1][1] == "hybrid"
+    assert got[1][2] == [] and got[1][3] == 0                       # rank 1 switched by itself
+    (move, why), = got[0][2]
+    assert move == 4 and "another rank" in why and got[0][3] == 1   # the first sync index (every 2 moves) after move 3

@@ -277,7 +277,7 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
             assert L.crl_trunk_forward_indexed(st, filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
                                                vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()),
                                                vp(m._head_b.data_ptr()), vp(hp.data_ptr()), vp(lst.data_ptr()),
-                                               vp(ws.data_ptr() if ws is not None else None)) == 0
+                                               vp(ws.data_ptr() if ws is not None else None), ws.numel() if ws is not None else 0) == 0
             torch.cuda.synchronize()
             mask = torch.zeros(n, dtype=torch.bool, device="cuda")
             mask[pick] = True
@@ -472,7 +472,8 @@ def test_trunk_outputs_do_not_change_while_another_process_uses_the_gpu(disturba
                     vp(torch.cuda.current_stream().cuda_stream), filters, vp(planes.data_ptr()), vp(m._wtiles3.data_ptr()),
                     vp(m._wbias.data_ptr()), n, blocks, vp(m._head_w.data_ptr()), vp(m._head_b.data_ptr()),
                     vp(hp.data_ptr()), vp(lst.data_ptr()),
-                    vp(m._trunk_workspace(n).data_ptr() if m._trunk_workspace(n) is not None else None)) == 0
+                    vp(m._trunk_workspace(n).data_ptr() if m._trunk_workspace(n) is not None else None),
+                    m._trunk_workspace(n).numel() if m._trunk_workspace(n) is not None else 0) == 0
                 torch.cuda.synchronize()
                 seen.add(hashlib.md5(hp.cpu().numpy().tobytes()).hexdigest())
             assert len(seen) == 1, (blocks, filters, n, "indexed", len(seen))

@@ -32,7 +32,7 @@ if mode == "indexed":
         rc = _lib.lib().crl_trunk_forward_indexed(
             vp(torch.cuda.current_stream().cuda_stream), filters, vp(bits.data_ptr()), vp(m._wtiles3.data_ptr()),
             vp(m._wbias.data_ptr()), B, blocks, vp(m._head_w.data_ptr()), vp(m._head_b.data_ptr()), vp(hp.data_ptr()),
-            vp(lst.data_ptr()), vp(ws.data_ptr() if ws is not None else None))
+            vp(lst.data_ptr()), vp(ws.data_ptr() if ws is not None else None), ws.numel() if ws is not None else 0)
         assert rc == 0
 else:
     for _ in range(3):
