@@ -1,8 +1,8 @@
 // tower_common.hpp -- fused residual trunk of the policy/value tower for gfx950 (MFMA, fp16 in,
 // fp32 accumulate): the design, and the types, constants and helpers the trunk kernels share.
 // The production kernels are tower_x16.hpp (v_mfma_f32_16x16x32_f16; 64, 128 and 256 filters).
-// The round-1 kernels on v_mfma_f32_32x32x16_f16 (first build, 128-filter pipeline, F-template)
-// live in tools/ubench/r1_kernels/ and are compiled only by the tuning harness there.
+// (The round-1 kernels on v_mfma_f32_32x32x16_f16 and their tuning harness are in the git history up to round 5:
+// tools/ubench/r1_kernels/, trunk_variants.hip.)
 //
 // Replaces the trunk of ChessModel (/root/reference/src/chessrl/model.py:33-37,111-122: stem
 // Conv3x3 + N x [Conv3x3-BN-ReLU-Conv3x3-BN-add-ReLU]) for inference.  BatchNorm is folded into

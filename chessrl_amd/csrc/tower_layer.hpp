@@ -48,21 +48,22 @@
 
 namespace crl_tower {
 
-// NB boards per workgroup: 4 (full batches: a wave owns one board x 128 channels) or 2 (the hybrid mode's indexed fall-back
-// launches and batches of at most 512 boards: twice the workgroups, a wave owns one board x 64 channels -- 4 x 4 accumulator
-// blocks --, every output accumulated in the same order: the same bits).
+// NB boards per workgroup: 4 (full batches: a wave owns one board x 128 channels), 2 (batches of at most 512 boards: twice the
+// workgroups, a wave owns one board x 64 channels -- 4 x 4 accumulator blocks) or 1 (eight waves x 32 channels of one board:
+// the geometry for launches of a few hundred boards on 256 CUs, where the time of a launch is ONE workgroup's); every
+// output is accumulated in the same order in all three: the same bits.
 template <int NB_>
 struct LayerGeoT {
-    static_assert(NB_ == 4 || NB_ == 2, "boards per workgroup");
+    static_assert(NB_ == 4 || NB_ == 2 || NB_ == 1, "boards per workgroup");
     static constexpr int F = 256, NB = NB_, ROWS = NB * 64, TAPS = 9;
-    static constexpr int CT = NB == 4 ? 8 : 4;           // 16-channel blocks per wave
+    static constexpr int CT = 2 * NB;                    // 16-channel blocks per wave: 8, 4, 2
     static constexpr int WPB = 8 / NB;                   // waves per board
     static constexpr int GROW = 128;                     // bytes of a row in the global image: hi 32 | lo 32 halves
     static constexpr int AROW = 160;                     // ... in LDS: + 32 B pad = 10 sixteen-byte units: the 16 lanes of a
                                                          // ds_read_b128 group (8 rows at quarter q, 8 at q + 1) cover all 64 banks
     static constexpr int ACHUNK = ROWS * AROW;           // 40 KiB (20 KiB)
-    static constexpr int APIECES = NB == 4 ? 5 : 3;      // 1-KiB DMA pieces per wave and chunk (NB 2: 24 pieces for 20 KiB,
-    static constexpr int ABUF = APIECES * 8 * 1024;      // the last four land in a tail nobody reads)
+    static constexpr int APIECES = NB == 4 ? 5 : (NB == 2 ? 3 : 2);   // 1-KiB DMA pieces per wave and chunk (NB 2: 24 pieces for
+    static constexpr int ABUF = APIECES * 8 * 1024;      // 20 KiB, NB 1: 16 for 10 KiB; the surplus lands in a tail nobody reads)
     static constexpr int ZERO_OFF = 2 * ABUF;
     static constexpr int ZERO_BYTES = 16 * AROW;
     static constexpr int WRING_OFF = ((ZERO_OFF + ZERO_BYTES + 1023) / 1024) * 1024;

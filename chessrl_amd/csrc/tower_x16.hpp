@@ -1,5 +1,5 @@
 // tower_x16.hpp -- the fused residual trunk (design: tower_common.hpp) on v_mfma_f32_16x16x32_f16
-// (the round-1 kernels on v_mfma_f32_32x32x16_f16 are tools/ubench/r1_kernels/, harness only).
+// (the round-1 kernels on v_mfma_f32_32x32x16_f16 left the tree in round 6; git history has them).
 //
 // Why: the trunk is matrix-pipe bound on a POWER-limited clock.  With the same 64x64 wave tile,
 // the same LDS bytes per MAC and the same 64 accumulator registers, a 16x16x32 loop sustains
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void k_trunk_x16(const unsigned char *__res
                                                        float *__restrict__ head_out)
 {
 #if !defined(CRL_HARNESS)
-    static_assert(ALT == 0, "diagnostic variants are for tools/ubench/trunk_variants.hip only");
+    static_assert(ALT == 0, "diagnostic variants are for the harnesses under tools/ubench/ only");
 #endif
     typedef Geo16<F, NB, SPLIT> G;
     static_assert(!SPLIT || (!GROUP && (ALT == 0 || ALT == 2)), "split precision runs the plain / pair pipelines");

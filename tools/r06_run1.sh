@@ -14,3 +14,5 @@ rm -rf /tmp/st_c5g
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_c5g -- python3 $R/bench.py --blocks 20 --filters 256 --steps-per-graph 1 --steps 40 --warmup 10 --no-cpu-baseline --parity-positions 0 --strict-steps 0 --gph-seconds 0 > $R/$O/bench_c5_graph_profiled.json 2> $R/$O/bench_c5_graph_profiled.err; echo "rocprof c5 spg1 rc $?"
 find /tmp/st_c5g -name "*kernel_stats.csv" -exec cp {} $R/$O/bench_c5_graph_kernel_stats.csv \;
 ls -la $R/$O
+cd $R
+timeout 300 ./tools/ubench/conv_indexed 4096 10 > $O/conv_indexed_harness.log 2>&1; echo "indexed harness rc $?"; cat $O/conv_indexed_harness.log
