@@ -104,6 +104,10 @@ def parse():
                    help="steps of the stamped leg behind the timed window: the same step captured WITH one-thread stamp "
                         "kernels between its phases and around every trunk launch, replayed as a hipGraph -- phase and "
                         "kernel times of roofline.step_fit come from the replayed graph (0 = skip: eager HIP events only)")
+    p.add_argument("--opening-moves", type=int, default=6,
+                   help="shortened, noisy moves every game plays (un-timed) before the window, so that the games are on "
+                        "lines of their own as in every later move of a real run (see play_opening)")
+    p.add_argument("--opening-sims", type=int, default=32, help="simulations of each opening move")
     p.add_argument("--gph-seconds", type=float, default=14.0,
                    help="seconds of the games/hour leg behind the timed region (rank 0, N = 1): COMPLETE games at C2's size "
                         "(512 in lockstep, 100 sims/move, 6x64 random-init, refill), the first quarter un-counted while "
@@ -349,40 +353,66 @@ def profile_phases(run, n):
     return out
 
 
-def graph_phases(run, n):
-    """Phase and trunk-launch times of ``n`` steps taken from the REPLAYED hipGraph: the engine captures the same
-    step with one-thread stamp kernels (crl_stamp: id + device wall clock into a ring) between its phases and the
-    model brackets every trunk launch with two more; consecutive stamps telescope to the step, so the parts add up
-    to the stamped step exactly, and that step against the un-stamped timed one shows what the stamps cost.  Mid-move
-    like the timed window.  None without graphs."""
-    from chessrl_amd.engine import StampRing, summarise_stamps
+def stamped_steps(run, ring, n):
+    """``n`` (a multiple of the steps per graph launch) lockstep steps of the STAMPED build of the step (engine.set_stamps:
+    one-thread crl_stamp kernels between the phases and around every trunk launch, captured into the hipGraph with them),
+    continuing the move under way when it has room for them -- the stamped leg then sees the trees the timed window has
+    just left -- else in the next move, grown un-stamped to its middle.  Leaves the engine on the plain graphs."""
+    eng = run.engine
+    if run._sims_in_move is None or run.sims - run._sims_in_move < n + 1:
+        if run._sims_in_move:
+            run.end_move()                                 # (the games go on: the next move is a real one)
+        run.steps(min(run.sims // 2 + 8, run.sims - n - 1))
+    eng.set_stamps(ring)
+    try:
+        eng.run_steps(n)
+    finally:
+        eng.set_stamps(None)
+    run._sims_in_move += n
+
+
+def graph_phases_begin(run, n):
+    """Before the timed window: the ring, the stamped graphs (captured now: nothing is captured between the window and
+    the stamped leg) and one warm replay of them.  Returns (ring, steps of the leg) or None without graphs."""
+    from chessrl_amd.engine import StampRing
     eng = run.engine
     if not eng.use_graph or n <= 0:
         return None
-    run.begin_move()                                       # fresh trees (a move under way is abandoned: the legs behind
-    K = eng.STEPS_PER_GRAPH                                # the timed window only measure)
+    K = eng.STEPS_PER_GRAPH
     n = max(K, min(n, run.sims // 3) // K * K)
-    grow = max(0, min(run.sims // 2 + 8, run.sims - n - K - 1))
-    eng.run_steps(grow)                                    # un-stamped, to trees of the timed window's depth
     ring = StampRing((n + 2 * K) * 16, eng.dev)
-    eng.set_stamps(ring)
-    try:
-        eng.prepare_graphs(n)                              # capture the stamped step (nothing is launched)
-        eng.run_steps(K)                                   # one warm replay
-        torch.cuda.synchronize()
-        ring.clear()
-        t0 = time.perf_counter()
-        eng.run_steps(n)
-        stamps = ring.read()
-        wall_ms = (time.perf_counter() - t0) * 1e3 / n
-    finally:
-        eng.set_stamps(None)                               # (drops the stamped graphs)
-    run._sims_in_move = grow + K + n
+    stamped_steps(run, ring, K)                            # captures the stamped K-step graph and replays it once
+    return ring, n
+
+
+def graph_phases_end(run, ring, n):
+    """Right behind the timed window: ``n`` stamped steps replayed from the hipGraph, the ring read back.  Phase and
+    trunk-launch times come from the REPLAYED graph: consecutive stamps telescope to the step, so the parts add up to
+    the stamped step exactly, and that step against the un-stamped timed one shows what the stamps cost."""
+    from chessrl_amd.engine import summarise_stamps
+    eng = run.engine
+    torch.cuda.synchronize()
+    ring.clear()
+    t0 = time.perf_counter()
+    stamped_steps(run, ring, n)
+    stamps = ring.read()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / n
     out = summarise_stamps(stamps)
     out["host_wall_ms_per_step"] = wall_ms
     out["source"] = ("crl_stamp kernels captured into the step's hipGraph (%d steps per graph launch), %d steps replayed "
-                     "mid-move, device wall clock at %.0f kHz" % (K, n, ring.ticks_per_ms))
+                     "right behind the timed window, device wall clock at %.0f kHz" % (eng.STEPS_PER_GRAPH, n, ring.ticks_per_ms))
     return out
+
+
+def graph_phases(run, n):
+    """Both halves in one go (the legs behind the main window: another precision mode's phases)."""
+    got = graph_phases_begin(run, n)
+    if got is None:
+        return None
+    try:
+        return graph_phases_end(run, *got)
+    finally:
+        run.engine.drop_stamped_graphs()
 
 
 def pmc_traffic(kernel, shape):
@@ -556,11 +586,30 @@ def dry_run(a, rank, world, dist):
               flush=True)
 
 
-def timed_window(run, a, barrier, model=None, sync=None):
+def play_opening(run, moves, sims):
+    """``moves`` shortened moves of ``sims`` simulations each, Dirichlet noise on (un-timed).  Every game starts from the
+    standard position and a search is deterministic, so without this all games of one colour hold the SAME tree for
+    the whole first move -- and a first move cut to one simulation (rounds 1-5) has one root child, which the noisy
+    policy must choose: the timed window then sat in move 2 of 4096 games in two distinct positions.  The tower's
+    time does not care, but everything data-dependent does: the hybrid mode listed either no S1 board of a step or
+    every board of a colour (C5, round 6 run 1: 0.1 ... 5.7 ms per indexed launch inside one window).  A few noisy moves
+    put every game on its own line, as every later move of a real run is."""
+    sims = max(1, min(sims, run.sims))
+    for _ in range(moves):
+        if run._sims_in_move is None:
+            run.begin_move()
+        run.engine.run_steps(sims - run._sims_in_move)
+        run._sims_in_move = sims
+        run.end_move()                                     # (a shortened move draws its noise at the boundary)
+
+
+def timed_window(run, a, barrier, model=None, sync=None, stamped=0):
     """W un-timed warm-up steps, then EXACTLY K timed steps between barrier + synchronize pairs.  A window
-    shorter than a move is centred on the middle of a move (trees pre-grown un-timed); one shortened
-    move first (un-timed) loads every move-boundary kernel and host path once, so that a boundary timed
-    later is a steady-state one even when it is the first full-length boundary of the process.
+    shorter than a move is centred on the middle of a move (trees pre-grown un-timed); a few shortened, noisy
+    opening moves first (un-timed, ``play_opening``) put every game on a line of its own and load every
+    move-boundary kernel and host path once, so that a boundary timed later is a steady-state one.
+    ``stamped``: that many steps of the stamped build of the step are replayed right behind the window
+    (``graph_phases_end``; its graphs are captured and warmed in front of the window).
     ``model``: its counter of S1 boards evaluated twice (hybrid) is read INSIDE the window, next to the simulation
     counters -- behind the un-timed steps (round 5 read it in front of them and divided ~21 windows' worth of
     fall-back boards by one window's simulations).  The runner's precision guard is switched off for the window: a
@@ -568,16 +617,16 @@ def timed_window(run, a, barrier, model=None, sync=None):
     sync = sync or torch.cuda.synchronize
     guard_every, run.GUARD_EVERY = getattr(run, "GUARD_EVERY", 0), 0
     try:
-        return _timed_window(run, a, barrier, model, sync)
+        return _timed_window(run, a, barrier, model, sync, stamped)
     finally:
         run.GUARD_EVERY = guard_every
 
 
-def _timed_window(run, a, barrier, model, sync):
+def _timed_window(run, a, barrier, model, sync, stamped):
     if run._sims_in_move:                         # a second window (another precision mode): finish the move
         run.end_move()
-    run.step()
-    run.end_move()
+    # un-timed opening: the games leave their common line; it also loads every move-boundary kernel and host path
+    play_opening(run, getattr(a, "opening_moves", 1) if run.moves_played == 0 else 1, getattr(a, "opening_sims", 1))
     pre = 0
     if a.steps < a.sims:
         # mid-move; when the window fits into the second half of the move it starts just behind the
@@ -587,6 +636,7 @@ def _timed_window(run, a, barrier, model, sync):
         start = second_half if a.steps <= a.sims - second_half - 1 else (a.sims - a.steps) // 2
         pre = max(0, start - a.warmup)
     run.steps(pre + a.warmup)
+    gp = graph_phases_begin(run, stamped) if stamped else None      # (may move on into the next move: room for its leg)
     run.engine.prepare_graphs(a.steps)        # (nothing is captured inside the timed region)
     fallback = getattr(model, "fallback_boards", None) if getattr(model, "fused", False) else None
     w = {"pre": pre, "window_start": run._sims_in_move or 0, "moves0": run.moves_played,
@@ -604,6 +654,12 @@ def _timed_window(run, a, barrier, model, sync):
     w["sims"] = w["c1"]["sims"] - w["c0"]["sims"]          # simulations completed (backed up) in the timed region
     # fraction of the window's simulations whose S1 board went through the f16x3 fall-back (this rank's games)
     w["twice"] = (w["fb1"] - w["fb0"]) / max(1, w["sims"])
+    if gp is not None:
+        # the stamped leg, right behind the window: same trees, same clocks, no capture in between
+        try:
+            w["graph_phases"] = graph_phases_end(run, *gp)
+        finally:
+            run.engine.drop_stamped_graphs()
     return w
 
 
@@ -860,7 +916,8 @@ def main():
         per = every_rank(dist, [w["sims"], w["dt"]], rdev)
         return sum(p[0] for p in per), max(p[1] for p in per), [p[1] / a.steps * 1e3 for p in per]
 
-    win = timed_window(run, a, barrier, model)
+    n_stamped = a.graph_phase_steps if (rank == 0 and model.fused) else 0
+    win = timed_window(run, a, barrier, model, stamped=n_stamped)
     total_sims, max_dt, rank_ms = reduce_window(win)
     timed = {model.precision if model.fused else a.dtype: hybrid_entry({"simulations_per_s": total_sims / max_dt,
                                                                         "ms_per_step": max_dt / a.steps * 1e3}, model, win)}
@@ -880,7 +937,7 @@ def main():
         # the timed mode misses the bar on these weights: the headline is the rate of the mode the product
         # falls back to (every output under the bar evaluated in f16x3)
         model.set_precision(model.AUTO_STRICT)
-        win = timed_window(run, a, barrier, model)
+        win = timed_window(run, a, barrier, model, stamped=n_stamped)
         total_sims, max_dt, rank_ms = reduce_window(win)
         timed[model.precision] = hybrid_entry({"simulations_per_s": total_sims / max_dt,
                                                "ms_per_step": max_dt / a.steps * 1e3}, model, win)
@@ -911,7 +968,7 @@ def main():
         ms_step = max_dt / a.steps * 1e3
         boundary = time_move_boundary(run)               # rank 0 only; the other ranks wait at the last barrier
         ph = profile_phases(run, 16)                     # eager steps mid-move: every phase and every trunk launch
-        gp = graph_phases(run, a.graph_phase_steps) if model.fused else None   # the same from the replayed hipGraph
+        gp = win.get("graph_phases")                     # the same from the replayed hipGraph, right behind the timed window
         main_kind = model._trunk_mode() if model.fused else None     # the arithmetic of the roofline's kernel
         k_ms_b2b, in_step = k_ms, False
         if gp is not None and main_kind in gp["trunk"]:

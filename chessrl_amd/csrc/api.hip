@@ -7,6 +7,7 @@
 #include "heads.hpp"
 #include "train_ops.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -656,24 +657,28 @@ static bool trunk_is_layerwise(int filters, int flags)
 }
 
 extern "C++" {
-template <int NB>
+// NB boards per workgroup; IDX: 0 = the whole batch, 2 / 3 = the boards of the list when it is short / long (tower_layer.hpp)
+template <int NB, int IDX>
 static int layer_trunk_launch(hipStream_t st, bool bits, const void *planes, const void *wts, const void *bias, void *out_f32,
                               int n_boards, int n_blocks, const void *head_w, const void *head_b, void *head_out,
                               void *workspace, const int32_t *list)
 {
     typedef crl_tower::LayerGeoT<NB> G;
-    const int n_wg = n_boards / NB;
-    unsigned char *A = (unsigned char *)workspace, *B = A + (size_t)n_wg * G::ACT_WG_BYTES;
+    // a short list is at most IDX_SMALL_MAX boards: that many workgroups cover it (and an idle launch of them costs least)
+    const int n_wg = IDX == 2 ? std::min(n_boards / NB, crl_tower::IDX_SMALL_MAX / NB) : n_boards / NB;
+    // the two activation images: 64 KiB per board each, whatever the geometry
+    unsigned char *A = (unsigned char *)workspace, *B = A + (size_t)n_boards * (G::ACT_WG_BYTES / NB);
     typedef void (*conv_t)(const unsigned char *, const unsigned char *, const float *, unsigned char *, const int *,
                            const float *, const float *, float *, float *);
     typedef void (*expand_t)(const unsigned char *, unsigned char *, const int *);
-    const expand_t ex = list ? (bits ? (expand_t)crl_tower::k_layer_expand<1, 1, NB> : (expand_t)crl_tower::k_layer_expand<0, 1, NB>)
-                             : (bits ? (expand_t)crl_tower::k_layer_expand<1, 0, NB> : (expand_t)crl_tower::k_layer_expand<0, 0, NB>);
-    const conv_t stem = list ? (conv_t)crl_tower::k_layer_conv<4, 0, 1, NB> : (conv_t)crl_tower::k_layer_conv<4, 0, 0, NB>;
-    const conv_t c1 = list ? (conv_t)crl_tower::k_layer_conv<8, 1, 1, NB> : (conv_t)crl_tower::k_layer_conv<8, 1, 0, NB>;
-    const conv_t c2 = list ? (conv_t)crl_tower::k_layer_conv<8, 2, 1, NB> : (conv_t)crl_tower::k_layer_conv<8, 2, 0, NB>;
-    const conv_t c3 = list ? (conv_t)crl_tower::k_layer_conv<8, 3, 1, NB>
-                           : (out_f32 ? (conv_t)crl_tower::k_layer_conv<8, 4, 0, NB> : (conv_t)crl_tower::k_layer_conv<8, 3, 0, NB>);
+    const expand_t ex = bits ? (expand_t)crl_tower::k_layer_expand<1, IDX, NB> : (expand_t)crl_tower::k_layer_expand<0, IDX, NB>;
+    const conv_t stem = (conv_t)crl_tower::k_layer_conv<4, 0, IDX, NB>;
+    const conv_t c1 = (conv_t)crl_tower::k_layer_conv<8, 1, IDX, NB>;
+    const conv_t c2 = (conv_t)crl_tower::k_layer_conv<8, 2, IDX, NB>;
+    conv_t c3 = (conv_t)crl_tower::k_layer_conv<8, 3, IDX, NB>;
+    if constexpr (IDX == 0) {
+        if (out_f32) c3 = (conv_t)crl_tower::k_layer_conv<8, 4, 0, NB>;       // (tests: the fp32 trunk as well)
+    }
     for (conv_t k : { stem, c1, c2, c3 }) {
         hipError_t ea = allow_big_lds((const void *)k, G::LDS_BYTES);
         if (ea != hipSuccess) return fail(nullptr, CRL_ERR_HIP, hipGetErrorString(ea));
@@ -713,12 +718,19 @@ static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, co
     if (workspace_bytes < (size_t)2 * n_boards * (crl_tower::LayerGeo::ACT_WG_BYTES / 4))
         return fail(nullptr, CRL_ERR_ARG, "crl_trunk_forward: workspace_bytes is below crl_trunk_workspace_bytes(256, n_boards, "
                                            "CRL_TRUNK_SPLIT): the activation images of this batch would overrun the buffer");
-    // Four boards per workgroup for full batches; two for the indexed launches of the hybrid mode (a list is a few hundred
-    // boards: twice the workgroups on otherwise idle CUs, half the work each) and for batches of at most 512 boards.
-    // Every output is accumulated in the same order in both geometries: the same bits.
-    if (list || n_boards <= 512)
-        return layer_trunk_launch<2>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
-    return layer_trunk_launch<4>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
+    // Four boards per workgroup for full batches, two for batches of at most 512 boards.  The indexed launch of the hybrid mode
+    // (a list is a few hundred boards of 4096) enqueues BOTH of its geometries, one board per workgroup for a list of at most
+    // 256 boards and two beyond; the list, on the device, decides which sequence works (tower_layer.hpp: IDX 2 / 3).
+    // Every output is accumulated in the same order in all three geometries: the same bits.
+    if (list) {
+        const int rc = layer_trunk_launch<1, 2>(st, bits, planes, wts, bias, nullptr, n_boards, n_blocks, head_w, head_b, head_out,
+                                                workspace, list);
+        if (rc != CRL_OK) return rc;
+        return layer_trunk_launch<2, 3>(st, bits, planes, wts, bias, nullptr, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
+    }
+    if (n_boards <= 512)
+        return layer_trunk_launch<2, 0>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
+    return layer_trunk_launch<4, 0>(st, bits, planes, wts, bias, out_f32, n_boards, n_blocks, head_w, head_b, head_out, workspace, list);
 }
 
 static int trunk_forward(void *hip_stream, int filters, const void *dev_planes_f16, int flags,

@@ -76,6 +76,21 @@ struct LayerGeoT {
 };
 typedef LayerGeoT<4> LayerGeo;
 
+// IDX (k_layer_expand, k_layer_conv): 0 = the launch covers the batch.  Else it covers the boards of a device list (the hybrid
+// mode's fall-back): 1 = whatever the list holds (harnesses); 2 = only a list of at most IDX_SMALL_MAX boards, 3 = only a longer
+// one -- a launch whose list is outside its window leaves on its first instructions.  The list's length exists on the device
+// only and the launch sequence of a captured hipGraph is fixed, so the product enqueues BOTH sequences behind one another -- one
+// board per workgroup (IDX 2, a grid of IDX_SMALL_MAX workgroups: one round of the 256 CUs, where a launch takes ONE workgroup's
+// time and that is 41 us per convolution instead of 65 at two boards) and two boards per workgroup (IDX 3: beyond one round
+// the larger tile wins, 134 against 171 us at 800 boards) -- and the list picks the one that works; the idle sequence costs
+// 41 x ~2 us (tools/ubench/conv_indexed.hip, profiles/r06/conv_indexed_harness.log).
+constexpr int IDX_SMALL_MAX = 256;
+template <int IDX>
+__device__ __forceinline__ bool idx_outside(int listed)
+{
+    return (IDX == 2 && listed > IDX_SMALL_MAX) || (IDX == 3 && listed <= IDX_SMALL_MAX);
+}
+
 // uniform 64-bit base in SGPRs + unsigned 32-bit lane offset (through readfirstlane so that hipcc does not fold the lane
 // offset into per-plane 64-bit lane addresses that it then hoists and spills)
 __device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p)
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__res
     for (int b = 0; b < NB; b++) rows[b] = blockIdx.x * NB + b;
     if constexpr (IDX) {
         const int listed = list[0];
-        if ((int)blockIdx.x * NB >= listed) return;
+        if ((int)blockIdx.x * NB >= listed || idx_outside<IDX>(listed)) return;
 #pragma unroll
         for (int b = 0; b < NB; b++) rows[b] = list[LIST_HEADER + (rows[b] < listed ? rows[b] : listed - 1)];
     }
@@ -174,7 +189,8 @@ __global__ __launch_bounds__(512) void k_layer_expand(const unsigned char *__res
 // (second); 3: as 2, and the tail of the tower: the three 1x1 head convolutions reduced to head_out f32 [n][192] (as
 // k_trunk_x16 leaves them); 4: as 3, and the trunk's output to out f32 [n][64][256] (tests; its own instance so that the
 // product's last layer carries neither the branch nor the registers).
-// IDX: the launch covers the list's boards (k_layer_expand); a workgroup beyond it leaves at once; head_out rows by the list.
+// IDX != 0: the launch covers the list's boards (k_layer_expand; the windows of IDX 2 / 3: above); a workgroup beyond the list
+// leaves at once; head_out rows by the list.
 template <int CHUNKS, int KIND, int IDX, int NB = 4>
 __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__restrict__ act_in,
                                                        const unsigned char *__restrict__ wts,
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     int listed = 0;
     if constexpr (IDX) {
         listed = __builtin_amdgcn_readfirstlane(list[0]);
-        if ((int)blockIdx.x * NB >= listed) return;    // before any DMA or barrier: the whole workgroup leaves
+        if ((int)blockIdx.x * NB >= listed || idx_outside<IDX>(listed)) return;    // before any DMA or barrier: the whole workgroup leaves
     }
     const unsigned char *act = act_in + (size_t)blockIdx.x * G::ACT_WG_BYTES;     // (the stem's image fills half a slot)
 

@@ -277,7 +277,8 @@ class LockstepEngine(object):
                 raise ValueError("steps_per_graph must be >= 1")
             self.STEPS_PER_GRAPH = int(steps_per_graph)      # (instance override of the class default)
         self.stamps = None                   # measurement: a StampRing -> every phase of a step is stamped (bench.py)
-        self._graphs = {}                    # steps per graph -> captured hipGraph
+        self._stamped_ring = None            # ... the ring the cached stamped graphs write into
+        self._graphs = {}                    # (steps per graph, stamped?) -> captured hipGraph
         self._graph_epoch = 0
         self._bind_stream()
 
@@ -362,12 +363,21 @@ class LockstepEngine(object):
         self.phase_tower_s2()
 
     def set_stamps(self, ring):
-        """Attach (or with None detach) a StampRing: the captured graphs are dropped either way, the next
-        ``run_steps`` captures the step with (without) its stamps."""
+        """Attach (or with None detach) a StampRing: ``run_steps`` then replays the STAMPED build of the step (captured
+        on first use, cached beside the plain graphs: switching between the two costs nothing, so a stamped leg can
+        follow a timed window without a capture in between).  Stamped graphs write into the ring they were captured
+        with: another ring drops them."""
+        if ring is not None and ring is not self._stamped_ring:
+            self._graphs = {k: g for k, g in self._graphs.items() if not k[1]}
+            self._stamped_ring = ring
         self.stamps = ring
         if hasattr(self.evaluator, "stamp_fn"):
             self.evaluator.stamp_fn = ring.stamp if ring is not None else None
-        self._graphs = {}
+
+    def drop_stamped_graphs(self):
+        self.set_stamps(None)
+        self._graphs = {k: g for k, g in self._graphs.items() if not k[1]}
+        self._stamped_ring = None
 
     # One hipGraph launch costs ~12 us between the last kernel of one graph and the first of the next (measured,
     # tools/graph_unroll_probe.py): nothing at C3 (0.5 %), 9 % of a C2 step.  So the engine also keeps a graph of
@@ -398,14 +408,14 @@ class LockstepEngine(object):
             if self.stamps is not None:
                 self.stamps.stamp(STAMP_GRAPH_END)
         self._bind_stream()
-        self._graphs[k] = g
+        self._graphs[(k, self.stamps is not None)] = g
         self._graph_epoch = getattr(self.evaluator, "graph_epoch", 0)
         return g
 
     @property
     def _graph(self):
         """the one-step graph (None until captured); assigning None drops every captured graph"""
-        return self._graphs.get(1)
+        return self._graphs.get((1, False))
 
     @_graph.setter
     def _graph(self, value):
@@ -418,7 +428,7 @@ class LockstepEngine(object):
         # says so through graph_epoch: the captured launches are stale, capture again
         if self._graphs and self._graph_epoch != getattr(self.evaluator, "graph_epoch", 0):
             self._graphs = {}
-        g = self._graphs.get(k)
+        g = self._graphs.get((k, self.stamps is not None))
         return g if g is not None else self._capture(k)
 
     def prepare_graphs(self, n_steps=None):

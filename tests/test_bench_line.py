@@ -39,7 +39,14 @@ class FakeRun(object):
         self.guard_seen = []
         ctx = types.SimpleNamespace(counters=lambda: {"sims": self.steps_run * self.G, "nodes": 0, "depth_sum": 0,
                                                       "branch_sum": 0, "evals": 0, "terminal_hits": 0})
-        self.engine = types.SimpleNamespace(ctx=ctx, prepare_graphs=lambda n=None: None)
+        self.engine = types.SimpleNamespace(ctx=ctx, prepare_graphs=lambda n=None: None, run_steps=self._raw_steps)
+        self.opening = []
+
+    def _raw_steps(self, n):
+        self.steps_run += n
+
+    def begin_move(self):
+        self._sims_in_move = 0
 
     def step(self):
         self.steps(1)
@@ -50,6 +57,7 @@ class FakeRun(object):
         self._sims_in_move = (self._sims_in_move or 0) + n
 
     def end_move(self):
+        self.opening.append(self._sims_in_move)
         self._sims_in_move = None
         self.moves_played += self.G
 
@@ -61,8 +69,9 @@ def test_hybrid_fraction_on_the_bench_line_does_not_depend_on_the_window_length(
     the fraction is per_step / G whatever K is."""
     run = FakeRun(G=64)
     model = FakeModel(run, per_step=4)
-    a = types.SimpleNamespace(steps=steps, sims=800, warmup=5)
+    a = types.SimpleNamespace(steps=steps, sims=800, warmup=5, opening_moves=6, opening_sims=32)
     w = bench.timed_window(run, a, lambda: None, model, sync=lambda: None)
+    assert run.opening[:6] == [32] * 6                       # six shortened, noisy opening moves in front of everything
     assert w["sims"] == steps * 64
     assert w["twice"] == pytest.approx(4 / 64)
     assert w["pre"] + a.warmup > 100 or steps >= 400          # (un-timed steps really ran in front of the window)

@@ -37,11 +37,13 @@ def test_stamps_captured_into_the_step_graph_leave_the_search_unchanged_and_tele
             ring.clear()                                             # (the root evaluation and the capture's warm-up stamped too)
         eng.run_steps(sims)
         eng.ctx.sim_backup(eng.pri_s2.data_ptr(), eng.val_s2.data_ptr())
-        rc = eng.root_children(["nchild", "visits", "values", "moves", "replies", "root_visits"])
+        rc = eng.ctx.root_children(["nchild", "visits", "values", "moves", "replies", "root_visits"])
         stamps = ring.read() if ring is not None else None
         if stamped:
             eng.set_stamps(None)
-            assert model.stamp_fn is None and not eng._graphs
+            assert model.stamp_fn is None and any(k[1] for k in eng._graphs)     # the stamped graphs stay cached ...
+            eng.drop_stamped_graphs()
+            assert not any(k[1] for k in eng._graphs)                            # ... until they are dropped
         eng.close()
         return rc, stamps
 

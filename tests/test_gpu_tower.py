@@ -261,14 +261,19 @@ def test_reply_margin_lists_the_close_calls_and_the_indexed_trunk_evaluates_exac
         assert got[1] == -5 and int(got[2:4].view(np.int64)[0]) == 2 ** 31 - 3 + int(got[0]) and len(listed) == got[0]
         assert listed - want <= set() or -1 in want
         assert (want - {-1}) <= listed and 5 in listed and not ({0, 1} & listed)
-    for blocks, filters, n in ((1, 64, 64), (1, 64, 1024), (1, 128, 64), (1, 256, 64)):
+    # (256 filters, 1024 boards: the layer-wise kernels' two indexed geometries -- one board per workgroup up to 256 listed
+    # boards, two beyond -- on both sides of that boundary)
+    for blocks, filters, n in ((1, 64, 64), (1, 64, 1024), (1, 128, 64), (1, 256, 64), (1, 256, 1024)):
         m = ChessModel(blocks=blocks, filters=filters, seed=5, precision="hybrid")
         planes = M._probe_bitplanes(m.device, 256)[:64].repeat(n // 64, 1).contiguous()
         planes[:, 3] ^= torch.arange(n, device="cuda")               # every board different
         _, h16 = m._run_fused(planes, precision="f16")
         _, h48 = m._run_fused(planes, precision="f16x3")
         assert not torch.equal(h16, h48)
-        for pick in ([0], [5, 17, 40], list(range(1, n, 3)), []):
+        picks = [[0], [5, 17, 40], list(range(1, n, 3)), []]
+        if n >= 512:
+            picks += [list(range(2, 2 + 256)), list(range(3, 3 + 257)), list(range(n))]
+        for pick in picks:
             lst = torch.zeros(_lib.LIST_HEADER + n, dtype=torch.int32, device="cuda")
             lst[0] = len(pick)
             lst[_lib.LIST_HEADER:_lib.LIST_HEADER + len(pick)] = torch.tensor(pick, dtype=torch.int32)[torch.randperm(len(pick))] if pick else 0

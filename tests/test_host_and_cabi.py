@@ -445,7 +445,7 @@ def test_trunk_kernels_lds_traffic_is_race_free_under_emulation(device_asm):
 
 
 @pytest.mark.parametrize("kernel", ["128,4,1,0,1,0,0,0", "64,2,1,0,0,0,0,0", "64,4,1,0,0,1,0,0", "128,2,1,0,1,0,1,0",
-                                    "layer:8,1,0,4", "layer:8,2,1,2"])
+                                    "layer:8,1,0,4", "layer:8,2,3,2", "layer:8,1,2,1"])
 def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     """Negative controls of the emulation: loosening a steady-state ``vmcnt`` wait by one, removing a tile
     barrier and loosening a fragment ``lgkmcnt`` wait by one must each be reported (pair ring, plain ring,
@@ -454,13 +454,14 @@ def test_lds_race_check_catches_seeded_pipeline_bugs(device_asm, kernel):
     family = "k_layer_conv" if kernel.startswith("layer:") else "k_trunk_x16"
     kernel = kernel.split(":")[-1]
     seg = {(f, t): sg for f, t, sg in chk.kernels_of(device_asm)}[(family, kernel)]
-    indexed = family == "k_layer_conv" and kernel.split(",")[2] == "1"     # a listed launch: one listed board + its padding
+    indexed = family == "k_layer_conv" and kernel.split(",")[2] != "0"     # a listed launch: one listed board + its padding
     kernarg = chk.layer_kernarg(int(kernel.split(",")[1]), indexed) if family == "k_layer_conv" else None
+    listed = chk.layer_listed(kernel.split(",")[2]) if family == "k_layer_conv" else None   # (IDX 3: a list beyond 256 boards)
 
     def run(lines):
         ins, labels = chk.parse_kernel(lines)
         try:
-            return chk.check_workgroup(ins, labels, 1, kernarg=kernarg, listed=1 if indexed else None)[0]
+            return chk.check_workgroup(ins, labels, 1, kernarg=kernarg, listed=listed)[0]
         except chk.EmuError as e:
             return ["stopped: %s" % e]
 

@@ -362,6 +362,10 @@ class Wave(object):
                 self.sset(t[0], None)
             else:
                 self.sset(t[0], (a | (1 << (b & 31))) if op == "s_bitset1_b32" else (a & ~(1 << (b & 31)) & MASK32))
+        elif op == "s_mulk_i32":                             # D = D * signext(simm16); SCC unchanged
+            a, k = g(t[0]), _imm(t[1]) & 0xFFFF
+            k = k - 0x10000 if k & 0x8000 else k
+            self.sset(t[0], None if a is None else (s32(a) * k) & MASK32)
         elif op in ("s_mul_i32", "s_mul_hi_u32", "s_mul_hi_i32"):
             a, b = g(t[1]), g(t[2])
             if a is None or b is None:
@@ -877,6 +881,11 @@ def layer_kernarg(kind, indexed):
             0x28: 0x50000000, 0x30: 0x60000000, 0x38: 0x70000000 if kind >= 3 else 0, 0x40: 0x78000000 if kind == 4 else 0}
 
 
+def layer_listed(idx):
+    """How many boards the emulated list of a k_layer_conv<.., .., IDX, ..> launch holds (None: not indexed)."""
+    return {"0": None, "1": 1, "2": 1, "3": 301}[str(idx)]
+
+
 def check_kernel(args):
     family, tmpl, seg, n_blocks = args
     ins, labels = parse_kernel(seg)
@@ -884,9 +893,9 @@ def check_kernel(args):
     try:
         if family == "k_layer_conv":
             # one launch = one convolution (the whole kernel is executed: 4 or 8 K-chunks x 9 taps); an indexed launch
-            # with one listed board runs with its padding
-            indexed = targs[2] == "1"
-            findings, stats = check_workgroup(ins, labels, 0, listed=1 if indexed else None,
+            # with one listed board runs with its padding (IDX 3 only works on a list beyond IDX_SMALL_MAX = 256 boards)
+            indexed = targs[2] != "0"
+            findings, stats = check_workgroup(ins, labels, 0, listed=layer_listed(targs[2]),
                                               kernarg=layer_kernarg(int(targs[1]), indexed))
         else:
             # an indexed kernel (8th template argument) takes its boards from a list: one listed board, so that a
