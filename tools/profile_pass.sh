@@ -5,7 +5,7 @@
 # domain); the program after -- is python3 itself.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=$R/gpurun_out/prof_$ROUND
 mkdir -p $O
 pmc() {   # name counter cmd...
@@ -47,7 +47,7 @@ pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
 for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20 --no-graph" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 --gph-seconds 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
   find /tmp/st_$name -name "*kernel_stats.csv" -exec cp {} $O/bench_${name}_kernel_stats.csv \;
   find /tmp/st_$name -name "*domain_stats.csv" -exec cp {} $O/bench_${name}_domain_stats.csv \;
 done
