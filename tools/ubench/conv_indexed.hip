@@ -46,9 +46,21 @@ static void unpack(const std::vector<_Float16> &img, int boards, std::vector<_Fl
                        &img[((((size_t)(b / NB) * 8 + c) * (NB * 64)) + (b % NB) * 64 + p) * 64], 128);
 }
 
+// mode 0: every convolution reads the SAME planes (2.4 MB: L2-hot after the first -- the first build of this harness, and
+// optimistic: a tower's 41 convolutions each read their own 2.4 MB, 97 MB in all, that the S2 forward's 31 GB of activation
+// traffic has flushed from the MALL since the last step); 1: 41 distinct plane sets, 1 GiB written before every tower (cold);
+// 2: as 1, and a kernel that reads all 97 MB once in front of the tower (inside the timed region): do MALL-warm planes help?
+__global__ void k_touch(const unsigned char *p, size_t bytes, unsigned *sink)
+{
+    unsigned acc = 0;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 64; i < bytes; i += (size_t)gridDim.x * blockDim.x * 64)
+        acc += p[i];
+    if (acc == 0xFFFFFFFFu) *sink = acc;
+}
+
 template <int NB>
 static double run_geo(int batch, int listed, int reps, const std::vector<_Float16> &logical, const unsigned char *d_w, const float *d_bias,
-                      std::vector<_Float16> &out_logical)
+                      std::vector<_Float16> &out_logical, int mode = 0, unsigned char *d_flush = nullptr, size_t flush_bytes = 0)
 {
     typedef LayerGeoT<NB> G;
     const int boards = (listed + NB - 1) / NB * NB;               // padded to whole workgroups (the product pads with the last entry)
@@ -67,12 +79,16 @@ static double run_geo(int batch, int listed, int reps, const std::vector<_Float1
     CK(hipFuncSetAttribute((const void *)c1, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     CK(hipFuncSetAttribute((const void *)c2, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     const int n_wg = batch / NB;
+    const size_t cb = mode ? LayerGeo::conv_bytes(8) : 0;         // distinct planes per convolution, or the same for all
+    unsigned *d_sink;
+    CK(hipMalloc(&d_sink, 4));
     auto tower = [&]() {                                           // 41 launches: conv1 A -> B, conv2 B -> A (in place + skip)
+        if (mode == 2) hipLaunchKernelGGL(k_touch, dim3(1024), dim3(256), 0, 0, d_w, (size_t)41 * LayerGeo::conv_bytes(8), d_sink);
         for (int l = 0; l < 20; l++) {
-            hipLaunchKernelGGL(c1, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_a, d_w, d_bias, d_b, d_list, nullptr, nullptr, nullptr, nullptr);
-            hipLaunchKernelGGL(c2, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_b, d_w, d_bias, d_a, d_list, nullptr, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL(c1, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_a, d_w + (2 * l) * cb, d_bias, d_b, d_list, nullptr, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL(c2, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_b, d_w + (2 * l + 1) * cb, d_bias, d_a, d_list, nullptr, nullptr, nullptr, nullptr);
         }
-        hipLaunchKernelGGL(c1, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_a, d_w, d_bias, d_b, d_list, nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(c1, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_a, d_w + 40 * cb, d_bias, d_b, d_list, nullptr, nullptr, nullptr, nullptr);
     };
     // one conv1 + conv2 for the bit comparison (from the pristine image)
     hipLaunchKernelGGL(c1, dim3(n_wg), dim3(512), G::LDS_BYTES, 0, d_a, d_w, d_bias, d_b, d_list, nullptr, nullptr, nullptr, nullptr);
@@ -87,11 +103,24 @@ static double run_geo(int batch, int listed, int reps, const std::vector<_Float1
     for (int round = 0; round < 3; round++) {
         tower();
         CK(hipDeviceSynchronize());
-        CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; i++) tower();
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (ms / reps < best) best = ms / reps;
+        if (mode == 0) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; i++) tower();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms / reps < best) best = ms / reps;
+        } else {
+            float total = 0;
+            for (int i = 0; i < reps; i++) {
+                CK(hipMemsetAsync(d_flush, i, flush_bytes, 0));   // what a step's S2 forward does to the caches
+                CK(hipEventRecord(e0));
+                tower();
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                total += ms;
+            }
+            if (total / reps < best) best = total / reps;
+        }
     }
     CK(hipGetLastError());
     CK(hipFree(d_a)); CK(hipFree(d_b)); CK(hipFree(d_list));
@@ -103,6 +132,7 @@ int main(int argc, char **argv)
     typedef Geo16<256, 1, 1> WG;
     const int batch = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 10;
     std::vector<_Float16> wimg(LayerGeo::conv_bytes(8) / 2);
+    const size_t flush_bytes = (size_t)1 << 30;
     const float scale = 1.0f / sqrtf(9.0f * 256);
     for (int c = 0; c < 8; c++)
         for (int t = 0; t < 9; t++)
@@ -118,7 +148,10 @@ int main(int argc, char **argv)
     std::vector<float> bias(256);
     for (auto &b : bias) b = frnd(0.1f);
     unsigned char *d_w; float *d_bias;
-    CK(hipMalloc(&d_w, wimg.size() * 2)); CK(hipMemcpy(d_w, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_w, 41 * wimg.size() * 2));
+    for (int l = 0; l < 41; l++) CK(hipMemcpy(d_w + (size_t)l * wimg.size() * 2, wimg.data(), wimg.size() * 2, hipMemcpyHostToDevice));
+    unsigned char *d_flush;
+    CK(hipMalloc(&d_flush, flush_bytes));
     CK(hipMalloc(&d_bias, 1024)); CK(hipMemcpy(d_bias, bias.data(), 1024, hipMemcpyHostToDevice));
     for (int listed : {0, 16, 100, 256, 400, 800, 1600}) {
         if (listed > batch) continue;
@@ -131,9 +164,17 @@ int main(int argc, char **argv)
                 logical[i + e] = (_Float16)v;
                 logical[i + 32 + e] = (_Float16)(v - (float)logical[i + e]);
             }
-        std::vector<_Float16> o1, o2;
+        std::vector<_Float16> o1, o2, o3;
         const double t2 = run_geo<2>(batch, listed, reps, logical, d_w, d_bias, o2);
         const double t1 = run_geo<1>(batch, listed, reps, logical, d_w, d_bias, o1);
+        if (listed > 0 && listed <= 800) {
+            const double c2 = run_geo<2>(batch, listed, reps, logical, d_w, d_bias, o3, 1, d_flush, flush_bytes);
+            const double c1 = run_geo<1>(batch, listed, reps, logical, d_w, d_bias, o3, 1, d_flush, flush_bytes);
+            const double w2 = run_geo<2>(batch, listed, reps, logical, d_w, d_bias, o3, 2, d_flush, flush_bytes);
+            const double w1 = run_geo<1>(batch, listed, reps, logical, d_w, d_bias, o3, 2, d_flush, flush_bytes);
+            printf("%5d listed, planes of their own per convolution, caches flushed before the tower:  NB 2 %7.3f ms  NB 1 %7.3f ms   |  + all planes "
+                   "read once in front (97 MB, timed): NB 2 %7.3f ms  NB 1 %7.3f ms\n", listed, c2, c1, w2, w1);
+        }
         const bool same = o1.size() == o2.size() && (o1.empty() || memcmp(o1.data(), o2.data(), o1.size() * 2) == 0);
         printf("%5d listed of %d: 41 indexed convolutions  NB 2: %7.3f ms (%6.1f us per conv)   NB 1: %7.3f ms (%6.1f us per conv)   "
                "delta %+.3f ms   conv1+conv2 bits %s\n", listed, batch, t2, t2 / 41 * 1e3, t1, t1 / 41 * 1e3, t1 - t2,
