@@ -723,6 +723,9 @@ static int layer_trunk_forward(hipStream_t st, bool bits, const void *planes, co
     // 256 boards and two beyond; the list, on the device, decides which sequence works (tower_layer.hpp: IDX 2 / 3).
     // Every output is accumulated in the same order in all three geometries: the same bits.
     if (list) {
+        // (the planes of the whole tower through the memory-side cache first: tower_layer.hpp, k_layer_touch)
+        hipLaunchKernelGGL(crl_tower::k_layer_touch, dim3(1024), dim3(256), 0, st, (const unsigned char *)wts,
+                           crl_tower::LayerGeo::conv_bytes(4) + (size_t)2 * n_blocks * crl_tower::LayerGeo::conv_bytes(8), (const int *)list);
         const int rc = layer_trunk_launch<1, 2>(st, bits, planes, wts, bias, nullptr, n_boards, n_blocks, head_w, head_b, head_out,
                                                 workspace, list);
         if (rc != CRL_OK) return rc;

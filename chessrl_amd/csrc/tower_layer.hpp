@@ -126,6 +126,21 @@ __device__ __forceinline__ void layer_stage_act(const unsigned char *act, lds_by
                                      (__attribute__((address_space(3))) void *)(lds + dst), 16, 0, 0);
 }
 
+// In front of an indexed tower: every weight plane of the tower read once (one dword per 64-byte line; nothing is kept).  A list
+// is a few dozen boards, so the 1 + 2 N convolutions behind it are latency-bound launches of a few dozen workgroups, each waiting
+// one tap ahead for 32 KiB of planes that the S2 forward of the previous step (31 GB of activation traffic) has long flushed
+// from the MALL: 2.5 ms per 41 convolutions at one board per workgroup with cold planes against 1.6 ms with hot ones.  Reading
+// the 97 MB through all 256 CUs first takes ~30 us and leaves them in the memory-side cache: 1.86 ms in all
+// (tools/ubench/conv_indexed.hip, profiles/r06/conv_indexed_harness_cold.log).  Leaves at once on an empty list.
+__global__ __launch_bounds__(256) void k_layer_touch(const unsigned char *__restrict__ wts, size_t bytes, const int *__restrict__ list)
+{
+    if (list[0] <= 0) return;
+    unsigned acc = 0;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 64; i < bytes; i += (size_t)gridDim.x * 256 * 64)
+        acc += *reinterpret_cast<const unsigned *>(wts + i);
+    asm volatile("" ::"v"(acc));
+}
+
 // The input planes of the listed / all boards as the first layer's activation image: [workgroup][chunk 4][row 256][hi 32 | lo
 // 32], hi = the 0/1 plane values, lo = 0 (the stem then runs the same three products as every other layer; the one against
 // lo adds exact zeros -- 1/123 of the tower's MFMAs for one kernel body less).
