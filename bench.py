@@ -636,10 +636,17 @@ def _timed_window(run, a, barrier, model, sync, stamped):
         start = second_half if a.steps <= a.sims - second_half - 1 else (a.sims - a.steps) // 2
         pre = max(0, start - a.warmup)
     run.steps(pre + a.warmup)
+    distinct = None
+    get_positions = getattr(run.engine.ctx, "get_positions", None)
+    if get_positions is not None:
+        # how many different root positions the window's moves start from (evidence for the opening: rounds 1-5 timed 4096
+        # games in TWO positions)
+        import numpy as np
+        distinct = int(len(np.unique(get_positions(), axis=0)))
     gp = graph_phases_begin(run, stamped) if stamped else None      # (may move on into the next move: room for its leg)
     run.engine.prepare_graphs(a.steps)        # (nothing is captured inside the timed region)
     fallback = getattr(model, "fallback_boards", None) if getattr(model, "fused", False) else None
-    w = {"pre": pre, "window_start": run._sims_in_move or 0, "moves0": run.moves_played,
+    w = {"pre": pre, "window_start": run._sims_in_move or 0, "moves0": run.moves_played, "distinct_roots": distinct,
          "c0": run.engine.ctx.counters(), "fb0": fallback() if fallback else 0}
     barrier()
     t0 = time.perf_counter()
@@ -1156,6 +1163,9 @@ def main():
                        "numpy_promotion": eng.numpy_promotion,
                        "parallelism": "games sharded, no collective on the hot path"},
             "window": {"untimed_steps_before": pre + a.warmup, "first_sim_of_move": window_start,
+                       "opening": "%d shortened moves of %d simulations, Dirichlet noise on, un-timed (play_opening)"
+                                  % (a.opening_moves, a.opening_sims),
+                       "distinct_root_positions": win.get("distinct_roots"), "games": G,
                        "move_boundaries_inside": inside,
                        "note": "a window shorter than one move is centred mid-move"},
             "per_rank": {"ms_per_step": spread(rank_ms), "trunk_launch_ms": spread(rank_k_ms)},

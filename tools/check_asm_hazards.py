@@ -174,6 +174,8 @@ def main(path):
         seg = seg[:end[-1] + 1] if end else seg
         bad, states = check(seg)
         m = re.search(r"\d+(k_[a-z0-9_]+?)I(.*?)EEv", name)
+        if m is None:                                        # (not a template: no hand-counted pipeline, e.g. k_layer_touch)
+            continue
         tmpl = m.group(2).replace("Li", "").replace("E", ",").rstrip(",")
         print("%s<%s>: %s" % (m.group(1), tmpl, "ok" if not bad else "%d instructions touch a register with a ds_read in flight" % len(bad)))
         for n, l in bad[:8]:
