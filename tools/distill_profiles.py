@@ -114,7 +114,7 @@ table = {"what": "HBM-side traffic per launch from rocprofv3 PMC passes (one cou
                  "the launch shape; bench.py emits traffic only for an exact match.",
          "passes": passes}
 json.dump(table, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-for n in ("c3", "c5", "c2"):
+for n in ("c3", "c5", "c5g", "c2"):
     for kind in ("kernel_stats.csv", "domain_stats.csv", "profiled.json"):
         src = os.path.join(SRC, "bench_%s_%s" % (n, kind))
         if os.path.exists(src):

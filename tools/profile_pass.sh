@@ -42,12 +42,16 @@ pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 
 pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
 pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0
 pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
-# (c5: --no-graph -- rocprofv3's kernel tracing of ROCm 7.2 segfaults inside hipGraphLaunch when a graph holds the ~1000 kernel
-# nodes of eight C5 hybrid steps (42 launches per layer-wise tower forward); eager launches run the same kernels)
-for cfg in "c3 --steps 800 --warmup 200" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20 --no-graph" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
+# (c5: --no-graph.  rocprofv3's kernel tracing of ROCm 7.2 aborted every hipGraph launch that held the layer-wise kernels of
+# rounds 5 / 6a -- "AQL packet is malformed", at one step per graph as well as at eight -- while graphs of 1024 plain kernel
+# nodes, of C3 hybrid steps and of C5 f16 steps trace fine: what those kernels had and nothing else in a step has was a private
+# segment (2 - 6 spilled VGPRs).  Since round 6b they have none (tower_layer.hpp: CRL_LAYER_ASM_MFMA); "c5g" traces graph-REPLAYED
+# C5 hybrid steps, one step per graph; the eager pass stays as the fallback)
+for cfg in "c3 --steps 800 --warmup 200" "c5g --blocks 20 --filters 256 --steps 40 --warmup 10 --steps-per-graph 1 --strict-steps 0" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20 --no-graph" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 --gph-seconds 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
+  lim=900; [ "$name" = c5g ] && lim=400        # (a tracer that aborts the queue leaves the process hanging)
+  timeout $lim rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$name -- python3 $R/bench.py --no-cpu-baseline --parity-positions 0 --gph-seconds 0 "$@" > $O/bench_${name}_profiled.json 2> $O/bench_${name}.err
   find /tmp/st_$name -name "*kernel_stats.csv" -exec cp {} $O/bench_${name}_kernel_stats.csv \;
   find /tmp/st_$name -name "*domain_stats.csv" -exec cp {} $O/bench_${name}_domain_stats.csv \;
 done
