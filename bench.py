@@ -376,9 +376,9 @@ def graph_phases_begin(run, n):
     the stamped leg) and one warm replay of them.  Returns (ring, steps of the leg) or None without graphs."""
     from chessrl_amd.engine import StampRing
     eng = run.engine
-    if not eng.use_graph or n <= 0:
-        return None
     K = eng.STEPS_PER_GRAPH
+    if not eng.use_graph or n <= 0 or run.sims < 4 * K:    # (a move too short to hold the warm replay and the leg)
+        return None
     n = max(K, min(n, run.sims // 3) // K * K)
     ring = StampRing((n + 2 * K) * 16, eng.dev)
     stamped_steps(run, ring, K)                            # captures the stamped K-step graph and replays it once
