@@ -46,8 +46,7 @@
 // hipcc (0, rounds 5's product) some MFMAs get another destination than their C operand, the accumulators wander, and at four
 // boards per workgroup 2 - 6 VGPRs end up in scratch (prologue values reloaded for the epilogue -- or, after an unrelated edit
 // of the epilogue, whole accumulator blocks at the tail of the tap loop).  Tied in place the kernels take 232 - 236 VGPRs and
-// no scratch at all, whatever the epilogue looks like.  Besides its cost, scratch is what rocprofv3's kernel tracing cannot
-// digest inside a hipGraph launch on this stack ("AQL packet is malformed": profiles/r06).
+// no scratch at all, whatever the epilogue looks like (same MFMA sequence: the GPU suite's bit comparisons are unchanged).
 #ifndef CRL_LAYER_ASM_MFMA
 #define CRL_LAYER_ASM_MFMA 1
 #endif

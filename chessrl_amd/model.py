@@ -142,6 +142,16 @@ def _probe_bitplanes(device, n):
     return _PROBE[key][:n]
 
 
+class _ClosingStamp(object):
+    """What ``ChessModel._trunk_event`` hands back while stamps are on: ``record()`` issues the stamp that closes the launch."""
+
+    def __init__(self, stamp_fn, sid):
+        self._fn, self._sid = stamp_fn, sid
+
+    def record(self):
+        self._fn(self._sid)
+
+
 class Tower(nn.Module):
     """Inference tower; input (B,128,8,8) channels_last fp16, i.e. NHWC memory."""
 
@@ -510,12 +520,7 @@ class ChessModel(object):
             from .engine import STAMP_TRUNK
             b, e = STAMP_TRUNK[kind]
             self.stamp_fn(b)
-            fn = self.stamp_fn
-
-            class _Close(object):
-                def record(self_inner):
-                    fn(e)
-            return (kind, None, _Close())
+            return (kind, None, _ClosingStamp(self.stamp_fn, e))
         if self.trunk_events is None:
             return None
         make = getattr(self, "trunk_event_cls", None) or torch.cuda.Event      # (bench.py: events without a system fence)

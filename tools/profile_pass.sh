@@ -42,11 +42,12 @@ pmc tree FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/tree_shape.json 
 pmc tree WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 1
 pmc treefull FETCH_SIZE python3 $R/tools/tree_once.py 4096 400 1 $O/treefull_shape.json 0
 pmc treefull WRITE_SIZE python3 $R/tools/tree_once.py 4096 400 1 - 0
-# (c5: --no-graph.  rocprofv3's kernel tracing of ROCm 7.2 aborted every hipGraph launch that held the layer-wise kernels of
-# rounds 5 / 6a -- "AQL packet is malformed", at one step per graph as well as at eight -- while graphs of 1024 plain kernel
-# nodes, of C3 hybrid steps and of C5 f16 steps trace fine: what those kernels had and nothing else in a step has was a private
-# segment (2 - 6 spilled VGPRs).  Since round 6b they have none (tower_layer.hpp: CRL_LAYER_ASM_MFMA); "c5g" traces graph-REPLAYED
-# C5 hybrid steps, one step per graph; the eager pass stays as the fallback)
+# (c5: --no-graph.  rocprofv3's kernel tracing of ROCm 7.2 does not survive a hipGraph launch that holds the layer-wise kernels:
+# "AQL packet is malformed" / SIGSEGV in a tracer thread, at ONE step per graph (~135 nodes) as at eight.  It is not the node count
+# (graphs of 1024 plain kernel nodes trace fine, so do C3 hybrid steps and C5 f16 steps) and not the private segment those kernels
+# had in round 5 (round 6's are scratch-free and die the same way): profiles/r06.  "c5g" is that attempt, kept so that a later
+# stack shows at once when it starts working; eager launches run the same kernels, and the in-graph times of a C5 step come from
+# bench.py's stamp kernels (roofline.step_fit))
 for cfg in "c3 --steps 800 --warmup 200" "c5g --blocks 20 --filters 256 --steps 40 --warmup 10 --steps-per-graph 1 --strict-steps 0" "c5 --blocks 20 --filters 256 --steps 100 --warmup 20 --no-graph" "c2 --games 512 --sims 100 --blocks 6 --filters 64 --steps 1600 --warmup 200"; do
   set -- $cfg; name=$1; shift
   rm -rf /tmp/st_$name
