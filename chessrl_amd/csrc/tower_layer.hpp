@@ -73,7 +73,14 @@ struct LayerGeoT {
     static constexpr int ZERO_BYTES = 16 * AROW;
     static constexpr int WRING_OFF = ((ZERO_OFF + ZERO_BYTES + 1023) / 1024) * 1024;
     static constexpr int TILE = F * 64;                  // one weight plane: [256 rows][64 B]
-    static constexpr int LDS_BYTES = WRING_OFF + 4 * TILE;
+    // plane ring: pairs (Whi, Wlo) of a (chunk, tap).  Two pairs: the planes of tap u + 2 are requested at the barrier of tap u and
+    // must have landed at the barrier of tap u + 1 -- one tap for an L2 / MALL round trip.  At four and two boards per workgroup a
+    // tap is 1.3 / 0.65 us of MFMAs and that is enough; at ONE board it is 0.32 us against ~0.5 us of latency, and the launch
+    // (the hybrid mode's indexed tower: its time is one workgroup's) ran at the latency, 0.53 - 0.64 us per tap.  There the ring
+    // holds THREE pairs (LDS has the room): requested three taps ahead, two taps to land, the barrier's wait leaves the youngest
+    // request in flight.  9 taps per chunk = 0 mod 3: the pair of a tap is t % 3, a compile-time number like the parity.
+    static constexpr int WPAIRS = NB == 1 ? 3 : 2;
+    static constexpr int LDS_BYTES = WRING_OFF + 2 * WPAIRS * TILE;
     static_assert(LDS_BYTES <= 160 * 1024 && ABUF >= ACHUNK, "LDS budget");
     static constexpr int CHUNK_BYTES = ROWS * GROW;      // one K-chunk of a workgroup's activations in the global image
     static constexpr int ACT_WG_BYTES = (F / 32) * CHUNK_BYTES;   // 64 KiB of (hi, lo) activations per board and layer
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     for (int j = 0; j < G::APIECES; j++) layer_stage_act<G>(act, lds, 0, 0, j, voff[j], wave_u);
     const unsigned woff[2] = {(unsigned)(tid * 16), (unsigned)(8192 + tid * 16)};
 #pragma unroll
-    for (int T = 0; T < 4; T++) layer_stage_w<G>(wts, lds, T, T, woff, wave_u);
+    for (int T = 0; T < 2 * G::WPAIRS; T++) layer_stage_w<G>(wts, lds, T, T, woff, wave_u);
     for (int i = tid; i < G::ZERO_BYTES / 16; i += 512)
         *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds + G::ZERO_OFF + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     };
     // weight fragment address: row obase + 16 ct + r of a plane, quarter q (the swizzle does not depend on ct)
     const int w0 = lds_base + G::WRING_OFF + (obase + r) * 64 + ((q ^ WG::wswz(obase + r)) << 4);
+    const int w0hi = w0 + 4 * G::TILE;                  // (a third pair lies beyond the 16-bit offset of ds_read_b128)
 
     wait_vmcnt_n<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -329,7 +337,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         constexpr int slot = decltype(SLOT)::value, half = decltype(HALF)::value;
         static_for<0, HC>([&](auto CC) {
             constexpr int c = decltype(CC)::value;
-            dst[c] = lds_read16_asm<slot * G::TILE + (half * HC + c) * 1024>(w0);
+            if constexpr (slot < 4) dst[c] = lds_read16_asm<slot * G::TILE + (half * HC + c) * 1024>(w0);
+            else dst[c] = lds_read16_asm<(slot - 4) * G::TILE + (half * HC + c) * 1024>(w0hi);
         });
     };
     auto mfma16 = [&](const half8 (&ww)[HC], const half8 (&xx)[PT], auto HALF) {
@@ -372,9 +381,14 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
     // kind (64 registers) beside the 128 accumulators.
     auto tap_body = [&](auto PC, int c, auto TC) {
         constexpr int P = decltype(PC)::value, t = decltype(TC)::value;
-        typedef std::integral_constant<int, 2 * P> SHI;
-        typedef std::integral_constant<int, 2 * P + 1> SLO;
-        typedef std::integral_constant<int, 2 * (1 - P)> SNEXT;
+        // ring pair of this tap: the parity with two pairs; t % 3 with three (9 taps per chunk: the same in every chunk)
+        constexpr int R = G::WPAIRS == 2 ? P : t % 3;
+        typedef std::integral_constant<int, 2 * R> SHI;
+        typedef std::integral_constant<int, 2 * R + 1> SLO;
+        typedef std::integral_constant<int, 2 * ((R + 1) % G::WPAIRS)> SNEXT;
+        // LDS-DMA instructions this wave issued at the PREVIOUS tap's barrier (4 plane pieces + one activation piece in the
+        // first APIECES taps of a chunk): with three pairs they may still be in flight at this tap's barrier
+        constexpr int YOUNGEST = G::WPAIRS == 2 ? 0 : 4 + ((t >= 1 && t - 1 < G::APIECES) ? 1 : 0);
         const int u = c * G::TAPS + t;
         // (no branch in the body: behind the last tap the prefetches read valid LDS that nobody uses, and the DMA requests
         // re-load the last planes / the last chunk into slots and a buffer that are dead -- a branch around inline-asm
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         wait_lgkm_n<PT>();
 #if defined(CRL_LAYER_STAMPS)
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-        wait_vmcnt_n<0>();
+        wait_vmcnt_n<YOUNGEST>();
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         st_vm += s1 - s0;
         st_sb += s2 - s1;
 #else
-        wait_vmcnt_n<0>();
+        wait_vmcnt_n<YOUNGEST>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -461,9 +475,9 @@ __global__ __launch_bounds__(512, 2) void k_layer_conv(const unsigned char *__re
         }
 #else
         {
-            const int un = u + 2 < CHUNKS * G::TAPS ? u + 2 : CHUNKS * G::TAPS - 1;
-            layer_stage_w<G>(wts, lds, 2 * un, 2 * P, woff, wave_u);
-            layer_stage_w<G>(wts, lds, 2 * un + 1, 2 * P + 1, woff, wave_u);
+            const int un = u + G::WPAIRS < CHUNKS * G::TAPS ? u + G::WPAIRS : CHUNKS * G::TAPS - 1;
+            layer_stage_w<G>(wts, lds, 2 * un, 2 * R, woff, wave_u);
+            layer_stage_w<G>(wts, lds, 2 * un + 1, 2 * R + 1, woff, wave_u);
         }
         if constexpr (t < G::APIECES) {
             // (the buffer of chunk c + 1 was last read in chunk c - 1, whose last barrier is behind us)
