@@ -86,7 +86,7 @@ for k in range(0, int(tl[-1, 1]) - N + 1, max(1, N // 4)):
     tb = tl[np.searchsorted(tl[:, 1], k + N, side="left"), 0]
     windows.append({"from_game": k, "seconds": float(tb - ta), "games_per_hour": N / (tb - ta) * 3600.0})
 out = {"games_in_lockstep": G, "sims_per_move": S, "tower": "%dx%d %s" % (TOWER[0], TOWER[1], model.precision),
-       "tower_precision_at_start": START_PRECISION, "tower_precision_guard": model.guard, "round_size": N, "rounds": rounds,
+       "tower_precision": model.precision, "tower_precision_at_start": START_PRECISION, "tower_precision_guard": model.guard, "round_size": N, "rounds": rounds,
        "training_in_the_loop": TRAIN, "trainer_share": SHARE if TRAIN else None, "weight_loads": loads, "trainer": trainer if TRAIN else None,
        "seconds_until_last_round_trained": (time.time() - t0) if TRAIN else None,
        "rounds_done": done, "seconds_total": total, "games_total": int(tl[-1, 1]), "sims_run": run.sims_run,
