@@ -72,9 +72,13 @@ def test_bench_one_rank_under_a_launcher_environment_takes_the_rccl_branch():
                MASTER_PORT="29654", CRL_BENCH_FORCE_GROUP="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6",
                           "--warmup", "2", "--games", "64", "--sims", "16", "--blocks", "2", "--filters", "64",
-                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline", "--gph-seconds", "3"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 1 and res["value"] > 0
+    # round 6's fields: the games left their common line before the window; games/hour is MEASURED in the run
+    assert res["window"]["distinct_root_positions"] > 32 and res["window"]["games"] == 64
+    gph = res["self_play_games_per_hour_measured"]
+    assert gph["seconds"] > 0 and gph["games"] >= 0 and gph["simulations_per_s"] > 0 and "C2" in gph["config"]
     g = res["record_gather"]
     assert g["backend"] == "nccl" and g["records"] == 64 and g["ms"] > 0
