@@ -22,6 +22,9 @@ for f in sorted(glob.glob("gpurun_out/seed_sweep/bench_%s_seed*.json" % TAG)):
                  "why": c["tower_precision_why"][:80], "simulations_per_s": d["value"], "ms_per_step": d["ms_per_step"],
                  "vs_fp32": {k: p[k] for k in ("positions", "dpolicy_max", "dvalue_max", "dvalue_p999", "positions_beyond_bar", "within_bar")},
                  "guard": c.get("tower_precision_guard"), "roofline_frac": r["frac"], "launch_ms": r["launch_ms"],
+                 "s1_boards_evaluated_twice": (d.get("precision_modes") or {}).get("hybrid", {}).get("s1_boards_evaluated_twice"),
+                 "distinct_root_positions": d["window"].get("distinct_root_positions"),
+                 "trunk_in_graph_ms": {k: v["launch_ms"] for k, v in (r.get("step_fit", {}).get("trunk_in_step") or {}).items()},
                  "step_fit_ratio": r.get("step_fit", {}).get("ratio")})
     print(rows[-1]["seed"], rows[-1]["mode"], round(rows[-1]["simulations_per_s"]), rows[-1]["vs_fp32"]["dvalue_max"], rows[-1]["guard"])
 json.dump({"what": "bench.py --seed s --steps 20 --warmup 5 %s (4096 games, 800 sims/move, random init; no extra flags = C3, 10x128), one line per seed" % EXTRA,
