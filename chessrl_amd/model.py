@@ -142,6 +142,14 @@ def _probe_bitplanes(device, n):
     return _PROBE[key][:n]
 
 
+class _DeviceArray(object):
+    """A raw device pointer as something ``torch.as_tensor`` understands (``__cuda_array_interface__``): the label /
+    count lists of the search kernels are known to the host as addresses only (crl_eval_labels)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 class _ClosingStamp(object):
     """What ``ChessModel._trunk_event`` hands back while stamps are on: ``record()`` issues the stamp that closes the launch."""
 
@@ -687,6 +695,64 @@ class ChessModel(object):
             return None
         d = float((pa[ok].log() - pb[ok].log()).abs().max())
         return d if np.isfinite(d) else None
+
+    @torch.no_grad()
+    def reply_rule_check(self, planes, labels_ptr, counts_ptr):
+        """The hybrid mode's reply rule, watched at run time on the run's own positions.  The rule: a board whose two best
+        LEGAL moves are at least ``reply_margin`` apart in log p (in f16) keeps its f16 reply; only closer calls are
+        evaluated again in f16x3.  It is an empirical rule (the margin is 2 x a SAMPLED arithmetic distance), so the same
+        hand-over that re-measures that distance also checks the rule itself: the positions are evaluated in both
+        arithmetics, the argmax over the legal labels (``labels_ptr`` uint16 [n,256] / ``counts_ptr`` int32 [n]: the
+        device lists the search kernels wrote for these positions) is taken in both, and every board whose choice differs
+        must be one the rule lists.  A board that is NOT listed and differs is a failure of the rule: it is counted
+        (``guard["reply_rule"]``), logged, and the margin is widened past that board's gap at once.  Costs two legal-prior
+        head passes beside margin_check's two trunk evaluations; returns the record of this check or None outside hybrid."""
+        import ctypes
+        from . import _lib
+        if not (self.fused and self.precision == "hybrid"):
+            return None
+        n = planes.shape[0]
+        vp = ctypes.c_void_p
+        stream = vp(torch.cuda.current_stream(self.device).cuda_stream)
+        pri = []
+        for mode in ("f16", "f16x3"):
+            _, hp = self._run_fused(planes, precision=mode)
+            out = torch.zeros((n, 256), dtype=torch.float32, device=self.device)
+            rc = _lib.lib().crl_heads_forward_legal(
+                stream, vp(hp.data_ptr()), n, vp(self._pol_wp.data_ptr()), vp(self._pol_bias.data_ptr()),
+                vp(self._val_w1p.data_ptr()), vp(self._val_b1.data_ptr()), vp(self._val_w2.data_ptr()), vp(labels_ptr),
+                vp(counts_ptr), vp(out.data_ptr()), None, vp(self._heads_scratch(n).data_ptr()))
+            if rc != 0:
+                raise _lib.HipLibraryError("crl_heads_forward_legal failed (%d)" % rc)
+            pri.append(out)
+        counts = torch.as_tensor(_DeviceArray(counts_ptr, (n,), "<i4"), device=self.device).clone()
+        legal = torch.arange(256, device=self.device)[None, :] < counts[:, None]
+        p16 = torch.where(legal, pri[0], torch.full_like(pri[0], -1.0))
+        p48 = torch.where(legal, pri[1], torch.full_like(pri[1], -1.0))
+        a16, a48 = p16.argmax(dim=1), p48.argmax(dim=1)              # (first maximum, as np.argmax / the kernels take it)
+        top2 = p16.topk(2, dim=1).values
+        gap = torch.log(top2[:, 0].clamp_min(1e-38)) - torch.log(top2[:, 1].clamp_min(1e-38))
+        listed = (counts >= 2) & ~(gap >= float(self.reply_margin))   # (a NaN gap is listed, as in k_reply_margin)
+        differ = (a16 != a48) & (counts >= 2)
+        unlisted = differ & ~listed
+        g = self.guard.setdefault("reply_rule", {"checks": 0, "boards": 0, "listed": 0, "replies_that_differ": 0,
+                                                 "differ_but_not_listed": 0, "largest_gap_of_a_differing_reply": 0.0})
+        g["checks"] += 1
+        g["boards"] += int((counts >= 2).sum())
+        g["listed"] += int(listed.sum())
+        g["replies_that_differ"] += int(differ.sum())
+        if bool(differ.any()):
+            g["largest_gap_of_a_differing_reply"] = max(g["largest_gap_of_a_differing_reply"], float(gap[differ].max()))
+        bad = int(unlisted.sum())
+        if bad:
+            g["differ_but_not_listed"] += bad
+            worst = float(gap[unlisted].max())
+            log.error("hybrid reply rule: %d of %d boards choose another reply in f16 than in f16x3 WITHOUT being listed "
+                      "(gap up to %.3e, margin %.3e): margin widened", bad, n, worst, self.reply_margin)
+            self.reply_margin = max(self.reply_margin, 1.25 * worst)
+            self._publish_reply_margin()
+            self.guard["margin"] = self.reply_margin
+        return {"boards": int((counts >= 2).sum()), "listed": int(listed.sum()), "differ": int(differ.sum()), "unlisted": bad}
 
     def _publish_reply_margin(self):
         """Write ``reply_margin`` into the device float crl_reply_margin reads (allocated once, rewritten in

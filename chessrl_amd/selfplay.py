@@ -250,6 +250,11 @@ class SelfPlayRunner(object):
                 before = getattr(eng.evaluator, "precision", None)
                 margin = getattr(eng.evaluator, "reply_margin", None)
                 d = check(eng.planes_s2)
+                rule = getattr(eng.evaluator, "reply_rule_check", None)
+                if before == "hybrid" and rule is not None and eng.legal_priors:
+                    # ... and the reply rule itself on the same positions: a board that chooses another reply in f16 than in
+                    # f16x3 must be one the margin lists (model.py: reply_rule_check; widens the margin at once if not)
+                    rule(eng.planes_s2, eng._lab_s2[0], eng._lab_s2[1])
                 if before == "hybrid" and getattr(eng.evaluator, "reply_margin", None) != margin:
                     log.info("hybrid reply margin widened from %.3e to %.3e (log-policy distance of f16 on this run's own "
                              "tree leaves)", margin, eng.evaluator.reply_margin)

@@ -137,3 +137,41 @@ def test_reply_margin_guards_zero_probabilities_a_cap_and_stickiness():
     m.load_dict(sharp)                                               # the next weight set of the run: stays strict
     assert m.precision == "hybrid" and m.precision_probe["sticky_after_guard"] and m.graph_epoch == epoch
     assert Lenient(weights=sharp).precision == "f16"                 # (another run starts afresh)
+
+
+def test_the_reply_rule_of_hybrid_is_watched_on_the_runs_own_positions_and_heals_itself():
+    """hybrid's reply rule (a board keeps its f16 reply unless its two best legal moves are closer than the margin) rests on
+    a SAMPLED distance; the hand-over that re-measures the distance also checks the rule: every board whose reply differs
+    between f16 and f16x3 must be one the margin lists.  With the product's margin no unlisted difference appears; with a
+    margin forced to nothing the differing boards ARE unlisted: counted, and the margin is widened past them at once."""
+    from chessrl_amd.model import ChessModel
+    from chessrl_amd.selfplay import SelfPlayRunner
+    from tests.test_gpu_tower import _positions
+    _, planes = _positions()
+    sharp = tower_oracle.calibrated_weights(6, 64, planes[:512], seed=7)
+    model = ChessModel(weights=sharp, precision="hybrid")
+    model.HYBRID_MIN_BOARDS = 0
+    run = SelfPlayRunner(model, n_parallel=512, sims=8, seed=3, noise=True, max_plies=512)
+    run.GUARD_EVERY = 1
+    for _ in range(6):
+        run.play_move()
+    rule = model.guard["reply_rule"]
+    assert rule["checks"] == 6 and rule["boards"] > 2000 and rule["listed"] > 0
+    assert rule["differ_but_not_listed"] == 0                          # the rule holds on this run's positions
+    assert rule["replies_that_differ"] >= 0 and rule["largest_gap_of_a_differing_reply"] < model.reply_margin
+    # a margin of nothing lists nobody: boards whose replies differ are now failures of the rule -- found and healed
+    eng = run.engine
+    seen = 0
+    for _ in range(40):
+        run.GUARD_EVERY = 0
+        run.play_move()
+        model.reply_margin = 1e-12
+        model._publish_reply_margin()
+        out = model.reply_rule_check(eng.planes_s2, eng._lab_s2[0], eng._lab_s2[1])
+        assert out["listed"] <= out["differ"] + 4                    # (next to nothing is listed under that margin)
+        if out["unlisted"]:
+            seen += out["unlisted"]
+            assert model.reply_margin >= 1.25 * 1e-12 and model.reply_margin > 1e-9       # widened past the failing board's gap
+            break
+    assert seen > 0 and model.guard["reply_rule"]["differ_but_not_listed"] == seen
+    run.close()
