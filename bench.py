@@ -670,11 +670,16 @@ def _timed_window(run, a, barrier, model, sync, stamped):
     return w
 
 
-def hybrid_entry(entry, model, win):
-    """What a timed window in ``hybrid`` adds to its precision_modes entry."""
+def hybrid_entry(entry, model, win, run=None):
+    """What a timed window in ``hybrid`` adds to its precision_modes entry.  With ``run``: the reply rule checked on the
+    window's last tree leaves (every board whose f16 and f16x3 replies differ must be one the margin lists;
+    ChessModel.reply_rule_check) -- un-timed, behind the window."""
     if getattr(model, "fused", False) and model.precision == "hybrid":
         entry["s1_boards_evaluated_twice"] = win["twice"]
         entry["reply_margin"] = model.reply_margin
+        eng = getattr(run, "engine", None)
+        if eng is not None and getattr(eng, "legal_priors", False) and hasattr(model, "reply_rule_check"):
+            entry["reply_rule_on_the_last_leaves"] = model.reply_rule_check(eng.planes_s2, eng._lab_s2[0], eng._lab_s2[1])
     return entry
 
 
@@ -927,7 +932,7 @@ def main():
     win = timed_window(run, a, barrier, model, stamped=n_stamped)
     total_sims, max_dt, rank_ms = reduce_window(win)
     timed = {model.precision if model.fused else a.dtype: hybrid_entry({"simulations_per_s": total_sims / max_dt,
-                                                                        "ms_per_step": max_dt / a.steps * 1e3}, model, win)}
+                                                                        "ms_per_step": max_dt / a.steps * 1e3}, model, win, run)}
 
     # ---- the headline carries its own parity evidence: the mode that was timed against the fp32 oracle on
     # the same weights, on positions of complete games played with those weights and on the positions the
@@ -947,7 +952,7 @@ def main():
         win = timed_window(run, a, barrier, model, stamped=n_stamped)
         total_sims, max_dt, rank_ms = reduce_window(win)
         timed[model.precision] = hybrid_entry({"simulations_per_s": total_sims / max_dt,
-                                               "ms_per_step": max_dt / a.steps * 1e3}, model, win)
+                                               "ms_per_step": max_dt / a.steps * 1e3}, model, win, run)
         if rank == 0:
             failed = parity
             parity = tower_error_vs_fp32(model, parity_sets, model.precision)
